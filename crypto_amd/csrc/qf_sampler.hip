@@ -1,0 +1,65 @@
+// Seeded counter-mode generator on the device (include/qfgpu.h "seeded generator").
+// Bit-identical to oracle/qf_oracle.c: qfo_sample_uniform / qfo_sample_bits / qfo_sample_noise.
+#include "qf_internal.h"
+
+__global__ void qf_sample_uniform_kernel(uint64_t base, uint64_t first, uint64_t count, uint32_t q,
+                                         uint32_t *__restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < count; i += stride) out[i] = qf_rand_below(base, first + i, q);
+}
+
+// one thread per output dword (32 bits); stride_bytes must be a multiple of 4
+__global__ void qf_sample_bits_kernel(uint64_t base, uint64_t first_row, uint64_t rows, uint32_t cols,
+                                      uint32_t stride_bytes, uint8_t *__restrict__ out) {
+    const uint32_t wpr = stride_bytes / 4;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t total = rows * wpr, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const uint64_t r = i / wpr;
+        const uint32_t j0 = (uint32_t)(i % wpr) * 32;
+        uint32_t word = 0;
+        for (uint32_t t = 0; t < 32; t++) {
+            uint32_t j = j0 + t;
+            if (j < cols) word |= (uint32_t)(qf_rand64(base, (first_row + r) * cols + j) & 1) << t;
+        }
+        ((uint32_t *)out)[i] = word;
+    }
+}
+
+__global__ void qf_sample_noise_kernel(uint64_t base, uint64_t first, uint64_t count, QfMod mod, uint32_t W,
+                                       uint32_t *__restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < count; i += stride) {
+        int64_t v = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) v += (int64_t)qf_rand_below(base, (first + i) * 4 + t, 2 * W + 1) - (int64_t)W;
+        out[i] = qf_red_i64(v, mod);
+    }
+}
+
+static unsigned sampler_grid(uint64_t n) {
+    uint64_t b = (n + 255) / 256;
+    return (unsigned)(b > 256 * 32 ? 256 * 32 : (b ? b : 1));
+}
+int qf_launch_sample_uniform(qf_ctx *ctx, uint64_t base, uint64_t first, uint64_t count, uint32_t q, uint32_t *out) {
+    if (!count) return QF_OK;
+    hipLaunchKernelGGL(qf_sample_uniform_kernel, dim3(sampler_grid(count)), dim3(256), 0, ctx->stream, base, first, count, q, out);
+    QF_HIP(ctx, hipGetLastError());
+    return QF_OK;
+}
+int qf_launch_sample_bits(qf_ctx *ctx, uint64_t base, uint64_t first_row, uint64_t rows, uint32_t cols,
+                          uint32_t stride_bytes, uint8_t *out) {
+    if (!rows) return QF_OK;
+    hipLaunchKernelGGL(qf_sample_bits_kernel, dim3(sampler_grid(rows * (stride_bytes / 4))), dim3(256), 0, ctx->stream,
+                       base, first_row, rows, cols, stride_bytes, out);
+    QF_HIP(ctx, hipGetLastError());
+    return QF_OK;
+}
+int qf_launch_sample_noise(qf_ctx *ctx, uint64_t base, uint64_t first, uint64_t count, const QfMod &mod, uint32_t W, uint32_t *out) {
+    if (!count) return QF_OK;
+    hipLaunchKernelGGL(qf_sample_noise_kernel, dim3(sampler_grid(count)), dim3(256), 0, ctx->stream, base, first, count, mod, W, out);
+    QF_HIP(ctx, hipGetLastError());
+    return QF_OK;
+}

@@ -1,0 +1,191 @@
+/*
+ * qfgpu.h -- C ABI of the MI355X (gfx950) implementation of qFALL-crypto's data-parallel
+ * lattice arithmetic.  This is the drop-in boundary: the reference has no FFI of its own
+ * (it calls qfall-math operator overloads, Cargo.toml:10), so every entry point below names
+ * the reference call site(s) it replaces (paths relative to /root/reference/src).  The Rust
+ * binding a maintainer would add on top of this header is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - q < 2^31; Z_q entries are canonical residues in [0,q) stored as uint32_t.
+ *   - Matrices are row-major.  Batches are message-major: X[b][cols], C[b][rows].
+ *   - Polynomials of R_q = Z_q[X]/(X^n+1) are n coefficients, degree-ascending.
+ *   - Bit vectors are LSB-first inside each byte.
+ *   - Pointers named *_dev are DEVICE pointers (hipMalloc / qf_malloc / torch .data_ptr());
+ *     pointers named *_host are host pointers.  Nothing is retained after a call returns
+ *     except inside the opaque handles.
+ *   - Every function returns QF_OK (0) or a QF_ERR_* code; qf_last_error(ctx) gives a text.
+ *     The reference panics where we return nonzero (bad dimension / modulus mismatch:
+ *     construction/hash/sis.rs:157-165); a binding turns codes back into panics.
+ *   - A context is bound to one device and one stream and is not re-entrant; work is
+ *     enqueued on the context's stream.  *_dev entry points are asynchronous w.r.t. the
+ *     host unless stated; *_host entry points synchronise before returning.
+ */
+#ifndef QFGPU_H
+#define QFGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    QF_OK = 0,
+    QF_ERR_ARG = 1,      /* null pointer / zero size / bad enum */
+    QF_ERR_DIM = 2,      /* dimension mismatch (reference: panic "mismatching dimensions") */
+    QF_ERR_MODULUS = 3,  /* q < 2, q >= 2^31, or modulus mismatch between operands */
+    QF_ERR_DEVICE = 4,   /* HIP runtime error */
+    QF_ERR_RANGE = 5,    /* an operand exceeded the range promised by the caller */
+    QF_ERR_NOTSUP = 6    /* parameter set outside what the kernels support */
+};
+
+/* how a batch operand X is encoded */
+enum {
+    QF_X_BITS = 0, /* {0,1}^cols bit-packed; row stride multiple of 16 bytes          */
+    QF_X_U32 = 1,  /* residues mod q as uint32_t (any value < 2^32 is reduced mod q)  */
+    QF_X_I32 = 2   /* signed integers as int32_t (reduced mod q)                      */
+};
+
+typedef struct qf_ctx qf_ctx;   /* device + stream + scratch                            */
+typedef struct qf_key qf_key;   /* a Z_q matrix resident on the device (MatZq operand)  */
+typedef struct qf_ring qf_ring; /* R_q = Z_q[X]/(X^n+1): n, q, twiddles                 */
+typedef struct qf_rkey qf_rkey; /* fixed polynomials of R_q prepared for multiplication */
+
+/* ------------------------------------------------------------------ context */
+const char *qf_version(void);
+int qf_device_count(int *count);
+/* stream: a hipStream_t (may be NULL = the device's default stream) */
+int qf_ctx_create(int device, void *stream, qf_ctx **out);
+int qf_ctx_set_stream(qf_ctx *ctx, void *stream);
+void qf_ctx_destroy(qf_ctx *ctx);
+int qf_sync(qf_ctx *ctx);
+const char *qf_last_error(const qf_ctx *ctx);
+/* plain device-memory helpers so a host language without HIP bindings can stage buffers */
+int qf_malloc(qf_ctx *ctx, size_t bytes, void **dev_out);
+int qf_free(qf_ctx *ctx, void *dev);
+int qf_memcpy_h2d(qf_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int qf_memcpy_d2h(qf_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* ------------------------------------------------------------------ Z_q matrix keys
+ * A qf_key is what the reference holds as a MatZq public key / SIS key:
+ *   Regev/LPR pk (n+1) x m      construction/pk_encryption/regev.rs:328-330, lpr.rs:316-318
+ *   DualRegev pk n x (m+1)      dual_regev.rs:327-329   (upload with transpose=1: enc is s^t*pk)
+ *   SISHash key n x m           construction/hash/sis.rs:52-54
+ * Upload recodes the matrix into signed radix-2^8 digit planes laid out in int8-MFMA
+ * fragment order (DESIGN.md "HBM layout") and keeps a uint32 copy for the single-message
+ * mat-vec path.  transpose != 0 stores the transpose of the given matrix. */
+int qf_key_upload_host(qf_ctx *ctx, const uint32_t *A_host, uint32_t rows, uint32_t cols,
+                       uint32_t q, int transpose, qf_key **out);
+int qf_key_upload_dev(qf_ctx *ctx, const uint32_t *A_dev, uint32_t rows, uint32_t cols,
+                      uint32_t q, int transpose, qf_key **out);
+void qf_key_destroy(qf_key *key);
+int qf_key_dims(const qf_key *key, uint32_t *rows, uint32_t *cols, uint32_t *q);
+/* device pointer + size of the row-major uint32 copy (rows x cols of the key as stored):
+ * this is the buffer a multi-GPU host broadcasts with RCCL before qf_key_upload_dev. */
+int qf_key_u32_dev(const qf_key *key, const uint32_t **dev_ptr, size_t *bytes);
+
+/* Kernel (a): batched product on int8 MFMA.
+ *   out[b][i] = sum_j key[i][j]*X[b][j]  (+ addend[b][i])  (+ (msg[b]&1)*floor(q/2) if i==rows-1)   mod q
+ * Replaces, for b = 0..B-1 at once:
+ *   Regev::enc      pk * vec_x, message into last entry        regev.rs:404-411   (X bits, msg)
+ *   LPR::enc        pk * vec_r + vec_e, message                lpr.rs:420-427     (X u32, addend, msg)
+ *   DualRegev::enc  (vec_s_t * pk + vec_e_t)^t, message        dual_regev.rs:403-410 (key uploaded transposed)
+ *   SISHash::hash   &self.key * value                          sis.rs:161-167     (no addend/msg)
+ *   PSFGPV::f_a     a * sigma                                  primitive/psf/gpv.rs:189-192
+ * x_stride_bytes: distance between consecutive rows of X.  x_digits: 0 = full width, or a
+ * promise that every centred entry of X fits in that many signed 8-bit digits (1..4); a broken
+ * promise is detected on the device and the product is redone at full width (never wrong).
+ * addend_dev / msg_dev may be NULL. */
+int qf_matmul_modq_dev(qf_ctx *ctx, const qf_key *key, const void *X_dev, int x_kind,
+                       size_t x_stride_bytes, int x_digits, uint64_t B,
+                       const uint32_t *addend_dev, const uint8_t *msg_dev, uint32_t *out_dev);
+
+/* Kernel (c): HBM-streaming single-message products (host vectors in/out, synchronous).
+ *   qf_matvec_modq_host : y = key * x          regev.rs:404, lpr.rs:420, sis.rs:166, dual_regev.rs:354
+ *   qf_vecmat_modq_host : y^t = x^t * key      regev.rs:367, lpr.rs:363, dual_regev.rs:403
+ * x has cols (resp. rows) entries, y rows (resp. cols). */
+int qf_matvec_modq_host(qf_ctx *ctx, const qf_key *key, const uint32_t *x_host, uint32_t *y_host);
+int qf_vecmat_modq_host(qf_ctx *ctx, const qf_key *key, const uint32_t *x_host, uint32_t *y_host);
+/* device-pointer forms (asynchronous) used by the benchmarks */
+int qf_matvec_modq_dev(qf_ctx *ctx, const qf_key *key, const uint32_t *x_dev, uint32_t *y_dev);
+int qf_vecmat_modq_dev(qf_ctx *ctx, const qf_key *key, const uint32_t *x_dev, uint32_t *y_dev);
+
+/* Batched decryption:  r_b = <w, C[b][0..n)> + C[b][n] mod q ;
+ *   bit_b = [dist(r_b,0) > dist(r_b, floor(q/2))]  (ring distance, ties -> 0)
+ * with w = -sk mod q supplied by the caller as canonical residues:
+ *   Regev::dec / LPR::dec   [-s ; 1] . c            regev.rs:438-452, lpr.rs:454-468
+ *   DualRegev::dec          c^t * [-x ; 1]          dual_regev.rs:437-450
+ * C is B x (n+1); bits_dev receives B bytes (0/1). */
+int qf_dot_decode_dev(qf_ctx *ctx, const uint32_t *w_dev, uint32_t n, uint32_t q,
+                      const uint32_t *C_dev, uint64_t B, uint8_t *bits_dev);
+
+/* ------------------------------------------------------------------ R_q
+ * qf_ring_create replaces utils/common_moduli.rs:41-48 (new_anticyclic): the ring X^n+1 mod q.
+ * n must be a power of two, 2 <= n <= 4096.  If q is prime with 2n | q-1 products use the
+ * negacyclic NTT (kernel b); for every other q they use an exact schoolbook kernel, so the
+ * reference's own parameter sets (ring_lpr.rs:312-314,343-345) work unchanged. */
+int qf_ring_create(qf_ctx *ctx, uint32_t n, uint32_t q, qf_ring **out);
+void qf_ring_destroy(qf_ring *ring);
+int qf_ring_info(const qf_ring *ring, uint32_t *n, uint32_t *q, int *uses_ntt);
+
+/* npoly fixed polynomials (canonical coefficients, npoly x n) prepared once:
+ *   RingLPR pk=(a,b), sk=s                    ring_lpr.rs:349-351
+ *   PSFGPVRing parity-check row a (k+2 polys) primitive/psf/gpv_ring.rs:66-92 */
+int qf_rkey_upload_host(qf_ctx *ctx, const qf_ring *ring, const uint32_t *polys_host,
+                        uint32_t npoly, qf_rkey **out);
+int qf_rkey_upload_dev(qf_ctx *ctx, const qf_ring *ring, const uint32_t *polys_dev,
+                       uint32_t npoly, qf_rkey **out);
+void qf_rkey_destroy(qf_rkey *rkey);
+
+/* Kernel (b): B independent products c_i = a_i * b_i in R_q.
+ * &PolynomialRingZq * &PolynomialRingZq   ring_lpr.rs:391,455,457,491 ; gpv_ring.rs:238 */
+int qf_polymul_dev(qf_ctx *ctx, const qf_ring *ring, const uint32_t *a_dev, const uint32_t *b_dev,
+                   uint64_t B, uint32_t *c_dev);
+
+/* RingLPR::enc for B messages (ring_lpr.rs:422-461), pk = rkey polys {0:a, 1:b}:
+ *   u_i = a*r_i + e1_i ; v_i = b*r_i + e2_i + mu_i(X)*floor(q/2)
+ * mu_bits_dev: B rows of ceil(n/8) bytes, bit k of row i = coefficient k of mu_i, i.e. the
+ * bits of |message| mod 2^n (ring_lpr.rs:424-427,318-329). */
+int qf_ringlpr_enc_dev(qf_ctx *ctx, const qf_ring *ring, const qf_rkey *pk, const uint32_t *r_dev,
+                       const uint32_t *e1_dev, const uint32_t *e2_dev, const uint8_t *mu_bits_dev,
+                       uint64_t B, uint32_t *u_dev, uint32_t *v_dev);
+/* RingLPR::dec (ring_lpr.rs:489-508), sk = rkey poly 0:
+ *   w = v - s*u ; bit_k = [dist(w_k, floor(q/2)) < dist(w_k, 0)] ; output packed like mu_bits. */
+int qf_ringlpr_dec_dev(qf_ctx *ctx, const qf_ring *ring, const qf_rkey *sk, const uint32_t *u_dev,
+                       const uint32_t *v_dev, uint64_t B, uint8_t *mu_bits_dev);
+
+/* GPV-ring FDH verification core for B signatures (signature/fdh.rs:115-123 minus the string
+ * hash; primitive/psf/gpv_ring.rs:235-239 f_a and :266-275 check_domain):
+ *   t_b = sum_j a_j * (sigma_b[j] mod q) ;  ok_b = [ sum sigma_b^2 <= norm_bound ] && [ t_b == u_b ]
+ * a = rkey with mbar = k+2 polys; sigma_dev: B x mbar x n signed coefficients (MatPolyOverZ);
+ * u_dev: B x n hashed targets (hash/sha256.rs:249-256); norm_bound = floor(s^2 * n*mbar).
+ * t_dev (B x n) may be NULL. */
+int qf_fdh_ring_verify_dev(qf_ctx *ctx, const qf_ring *ring, const qf_rkey *a, const int32_t *sigma_dev,
+                           const uint32_t *u_dev, uint64_t norm_bound, uint64_t B, uint32_t *t_dev,
+                           uint8_t *ok_dev);
+
+/* ------------------------------------------------------------------ seeded generator
+ * The reference samples from an unseeded RNG (e.g. regev.rs:352-364,401), so parity is defined
+ * on inputs produced by this counter-mode SplitMix64 generator, implemented identically in
+ * oracle/qf_oracle.c:  value = splitmix64((seed ^ (stream << 48)) + idx).
+ *   uniform : (value * q) >> 64                       for idx = first .. first+count-1
+ *   bits    : value & 1 at idx = (first_row+r)*cols + j, packed LSB-first, padding bits 0
+ *   noise   : sum of 4 uniform integers in [-W,W] (idx*4+t), stored mod q  (Gaussian stand-in) */
+int qf_sample_uniform_dev(qf_ctx *ctx, uint64_t seed, uint32_t stream, uint64_t first, uint64_t count,
+                          uint32_t q, uint32_t *out_dev);
+int qf_sample_bits_dev(qf_ctx *ctx, uint64_t seed, uint32_t stream, uint64_t first_row, uint64_t rows,
+                       uint32_t cols, uint32_t stride_bytes, uint8_t *out_dev);
+int qf_sample_noise_dev(qf_ctx *ctx, uint64_t seed, uint32_t stream, uint64_t first, uint64_t count,
+                        uint32_t q, uint32_t W, uint32_t *out_dev);
+
+/* ------------------------------------------------------------------ introspection for benches
+ * Average duration (ms) of the LAST launch of the dominant kernel of the named op, measured
+ * with HIP events on the context's stream when timing is enabled. */
+int qf_set_timing(qf_ctx *ctx, int enabled);
+int qf_last_kernel_ms(qf_ctx *ctx, const char *which /* "gemm","ntt","matvec","decode" */, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QFGPU_H */

@@ -1,0 +1,479 @@
+/*
+ * qf_oracle.c -- CPU restatement of qFALL-crypto's data-parallel lattice arithmetic.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it; the shipped GPU path never calls it.
+ *
+ * Every function restates, in plain C with 64/128-bit integers, what the reference
+ * computes through qfall-math (-> FLINT -> GMP, all absent from /root/reference and
+ * un-pinned: Cargo.toml:10, no Cargo.lock).  All values on this path are canonical
+ * residues in [0,q), q < 2^31, so exact integer arithmetic followed by a canonical
+ * reduction is bit-identical to FLINT's result.
+ *
+ * Parity pins (see tests/test_oracle_golden.py):
+ *   - rot_minus KATs               utils/rotation_matrix.rs:110-138
+ *   - fixed ring trapdoor (n=4,q=16) sample/g_trapdoor/short_basis_ring.rs:357-378 with
+ *     the identity a = [1 | a_bar | g^t - (a_bar*r + e)] of gadget_ring.rs:71-77
+ *   - SHA-256 / hash_to_zq / hash_to_mat_zq KATs   construction/hash/sha256.rs:35,60,104,270-332
+ *   - default / secure128 parameter sets and the round-trip semantics of the PKE tests.
+ * Scheme-level matrix/ring products themselves have NO known-answer test in the
+ * reference (all PKE/SIS/FDH tests are randomized round trips): for those the parity
+ * is "unpinned" and rests on the exactness argument above.
+ *
+ * Layout conventions (shared with the GPU library, include/qfgpu.h):
+ *   matrices row-major u32; batches are "message-major": X[b][cols], C[b][rows];
+ *   polynomials degree-ascending, n coefficients; bit vectors LSB-first in bytes.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+typedef unsigned __int128 u128;
+
+/* ------------------------------------------------------------------ helpers */
+
+static inline uint32_t addmod(uint32_t a, uint32_t b, uint32_t q) {
+    uint64_t s = (uint64_t)a + b;
+    return (uint32_t)(s >= q ? s - q : s);
+}
+static inline uint32_t submod(uint32_t a, uint32_t b, uint32_t q) {
+    return a >= b ? a - b : a + q - b;
+}
+static inline uint32_t mulmod(uint32_t a, uint32_t b, uint32_t q) {
+    return (uint32_t)(((uint64_t)a * b) % q);
+}
+static uint32_t powmod(uint32_t a, uint64_t e, uint32_t q) {
+    uint64_t r = 1 % q, b = a % q;
+    while (e) { if (e & 1) r = r * b % q; b = b * b % q; e >>= 1; }
+    return (uint32_t)r;
+}
+
+/* Zq::distance as used by the decision rules (regev.rs:447, ring_lpr.rs:500):
+ * ring (wrap-around) distance min(|a-x|, q-|a-x|)  (inferred upstream behaviour). */
+static inline uint32_t ring_dist(uint32_t a, uint32_t x, uint32_t q) {
+    uint32_t d = a >= x ? a - x : x - a;
+    return d < q - d ? d : q - d;
+}
+/* bit = 1 iff dist(r,0) > dist(r, floor(q/2))  (regev.rs:445-451); ties -> 0 */
+uint32_t qfo_decide_bit(uint32_t r, uint32_t q) {
+    return ring_dist(r, 0, q) > ring_dist(r, q / 2, q) ? 1u : 0u;
+}
+
+/* ------------------------------------------------------- seeded generator */
+
+static inline uint64_t sm64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+uint64_t qfo_rand64(uint64_t seed, uint32_t stream, uint64_t idx) {
+    return sm64((seed ^ ((uint64_t)stream << 48)) + idx);
+}
+/* uniform in [0,bound) by 64-bit multiply-high */
+static inline uint32_t rand_below(uint64_t seed, uint32_t stream, uint64_t idx, uint32_t bound) {
+    return (uint32_t)(((u128)qfo_rand64(seed, stream, idx) * bound) >> 64);
+}
+void qfo_sample_uniform(uint64_t seed, uint32_t stream, uint64_t first, uint64_t count,
+                        uint32_t q, uint32_t *out) {
+    for (uint64_t i = 0; i < count; i++) out[i] = rand_below(seed, stream, first + i, q);
+}
+/* bit-packed uniform bits: row r occupies stride_bytes bytes, bit j of row r comes from
+ * counter (first_row + r)*cols + j ; padding bits are zero */
+void qfo_sample_bits(uint64_t seed, uint32_t stream, uint64_t first_row, uint64_t rows,
+                     uint32_t cols, uint32_t stride_bytes, uint8_t *out) {
+    memset(out, 0, (size_t)rows * stride_bytes);
+    for (uint64_t r = 0; r < rows; r++)
+        for (uint32_t j = 0; j < cols; j++)
+            if (qfo_rand64(seed, stream, (first_row + r) * cols + j) & 1)
+                out[r * stride_bytes + (j >> 3)] |= (uint8_t)(1u << (j & 7));
+}
+/* Gaussian stand-in: sum of 4 independent uniform integers in [-W,W], stored mod q */
+void qfo_sample_noise(uint64_t seed, uint32_t stream, uint64_t first, uint64_t count,
+                      uint32_t q, uint32_t W, uint32_t *out) {
+    for (uint64_t i = 0; i < count; i++) {
+        int64_t v = 0;
+        for (int t = 0; t < 4; t++)
+            v += (int64_t)rand_below(seed, stream, (first + i) * 4 + t, 2 * W + 1) - (int64_t)W;
+        int64_t r = v % (int64_t)q;
+        if (r < 0) r += q;
+        out[i] = (uint32_t)r;
+    }
+}
+
+/* ------------------------------------------------ Z_q matrix products (kernels a, c) */
+
+/* y = A*x mod q, A rows x cols, x in Z_q^cols.
+ * regev.rs:404 (pk * vec_x), lpr.rs:420 (pk * vec_r), sis.rs:166 (&self.key * value),
+ * dual_regev.rs:354 (&mat_a * &vec_x), psf/gpv.rs:191. */
+void qfo_matvec(const uint32_t *A, uint32_t rows, uint32_t cols, uint32_t q,
+                const uint32_t *x, uint32_t *y) {
+    for (uint32_t i = 0; i < rows; i++) {
+        const uint32_t *a = A + (size_t)i * cols;
+        u128 acc = 0;
+        for (uint32_t j = 0; j < cols; j++) acc += (uint64_t)a[j] * x[j];
+        y[i] = (uint32_t)(acc % q);
+    }
+}
+/* y^t = x^t * A mod q, A rows x cols, x in Z_q^rows.
+ * regev.rs:367 (vec_s.transpose() * &mat_a), lpr.rs:363, dual_regev.rs:403 (vec_s_t * pk). */
+void qfo_vecmat(const uint32_t *A, uint32_t rows, uint32_t cols, uint32_t q,
+                const uint32_t *x, uint32_t *y) {
+    u128 *acc = (u128 *)calloc(cols, sizeof(u128));
+    for (uint32_t i = 0; i < rows; i++) {
+        const uint32_t *a = A + (size_t)i * cols;
+        uint64_t xi = x[i];
+        if (!xi) continue;
+        for (uint32_t j = 0; j < cols; j++) acc[j] += xi * a[j];
+    }
+    for (uint32_t j = 0; j < cols; j++) y[j] = (uint32_t)(acc[j] % q);
+    free(acc);
+}
+
+enum { QFO_X_BITS = 0, QFO_X_U32 = 1, QFO_X_I32 = 2 };
+
+static inline uint32_t x_entry(const void *X, int kind, size_t stride_bytes, uint64_t b,
+                               uint32_t j, uint32_t q) {
+    const uint8_t *row = (const uint8_t *)X + b * stride_bytes;
+    if (kind == QFO_X_BITS) return (row[j >> 3] >> (j & 7)) & 1u;
+    if (kind == QFO_X_U32) return ((const uint32_t *)row)[j] % q;
+    int64_t v = ((const int32_t *)row)[j] % (int64_t)q;
+    return (uint32_t)(v < 0 ? v + q : v);
+}
+
+/* Batched form of the products above, one message per row b:
+ *   out[b][i] = sum_j A[i][j]*X[b][j] (+ addend[b][i]) (+ (msg[b]&1)*floor(q/2) if i==rows-1)
+ * The trailing terms are the LPR noise (lpr.rs:420) and the message embedding into the LAST
+ * entry only (regev.rs:408-411, lpr.rs:424-427, dual_regev.rs:407-410). */
+void qfo_matmul_batch(const uint32_t *A, uint32_t rows, uint32_t cols, uint32_t q,
+                      const void *X, int xkind, size_t xstride_bytes, uint64_t B,
+                      const uint32_t *addend, const uint8_t *msg, uint32_t *out) {
+    uint32_t *x = (uint32_t *)malloc(sizeof(uint32_t) * cols);
+    for (uint64_t b = 0; b < B; b++) {
+        for (uint32_t j = 0; j < cols; j++) x[j] = x_entry(X, xkind, xstride_bytes, b, j, q);
+        uint32_t *c = out + b * rows;
+        qfo_matvec(A, rows, cols, q, x, c);
+        if (addend)
+            for (uint32_t i = 0; i < rows; i++) c[i] = addmod(c[i], addend[b * rows + i] % q, q);
+        if (msg && (msg[b] & 1)) c[rows - 1] = addmod(c[rows - 1], q / 2, q);
+    }
+    free(x);
+}
+
+/* Regev/LPR decryption (regev.rs:438-452, lpr.rs:454-468):
+ *   r = <[-s ; 1], c> mod q ; bit = [dist(r,0) > dist(r, floor(q/2))]
+ * s has n entries (canonical), each ciphertext n+1. */
+void qfo_dot_decode_batch(const uint32_t *s, uint32_t n, uint32_t q, const uint32_t *C,
+                          uint64_t B, uint8_t *bits) {
+    for (uint64_t b = 0; b < B; b++) {
+        const uint32_t *c = C + b * (n + 1);
+        u128 acc = c[n];
+        for (uint32_t i = 0; i < n; i++) acc += (uint64_t)(s[i] ? q - s[i] : 0) * c[i];
+        bits[b] = (uint8_t)qfo_decide_bit((uint32_t)(acc % q), q);
+    }
+}
+/* DualRegev decryption (dual_regev.rs:437-450): sk = x in {0,1}^m (MatZ, here any small
+ * signed ints as i32), r = c^t * [-x ; 1]. */
+void qfo_dualregev_decode_batch(const int32_t *x, uint32_t m, uint32_t q, const uint32_t *C,
+                                uint64_t B, uint8_t *bits) {
+    for (uint64_t b = 0; b < B; b++) {
+        const uint32_t *c = C + b * (m + 1);
+        __int128 acc = c[m];
+        for (uint32_t j = 0; j < m; j++) acc -= (__int128)x[j] * c[j];
+        __int128 r = acc % (__int128)q;
+        if (r < 0) r += q;
+        bits[b] = (uint8_t)qfo_decide_bit((uint32_t)r, q);
+    }
+}
+
+/* ------------------------------------------------ R_q = Z_q[X]/(X^n+1) (kernel b) */
+
+/* Rot^-(a): column j = coefficients of a*X^j mod X^n+1 (rotation_matrix.rs:45-67).
+ * Signed integer version for the KATs at rotation_matrix.rs:110-138. */
+void qfo_rot_minus_i64(const int64_t *a, uint32_t n, int64_t *out /* n*n row-major */) {
+    for (uint32_t i = 0; i < n; i++)
+        for (uint32_t j = 0; j < n; j++) {
+            uint32_t k = i + j;
+            if (k >= n) out[(size_t)(k % n) * n + j] = -a[i];
+            else out[(size_t)k * n + j] = a[i];
+        }
+}
+void qfo_rot_minus_modq(const uint32_t *a, uint32_t n, uint32_t q, uint32_t *out) {
+    for (uint32_t i = 0; i < n; i++)
+        for (uint32_t j = 0; j < n; j++) {
+            uint32_t k = i + j;
+            if (k >= n) out[(size_t)(k - n) * n + j] = a[i] ? q - a[i] : 0;
+            else out[(size_t)k * n + j] = a[i];
+        }
+}
+
+/* c = a*b in R_q, schoolbook: c_k = sum_{i+j=k} a_i b_j - sum_{i+j=k+n} a_i b_j.
+ * ring_lpr.rs:391,455,457,491 (&PolynomialRingZq * &PolynomialRingZq), gpv_ring.rs:238. */
+void qfo_polymul_negacyclic(const uint32_t *a, const uint32_t *b, uint32_t n, uint32_t q,
+                            uint32_t *c) {
+    for (uint32_t k = 0; k < n; k++) {
+        u128 pos = 0, neg = 0;
+        for (uint32_t i = 0; i <= k; i++) pos += (uint64_t)a[i] * b[k - i];
+        for (uint32_t i = k + 1; i < n; i++) neg += (uint64_t)a[i] * b[k + n - i];
+        c[k] = submod((uint32_t)(pos % q), (uint32_t)(neg % q), q);
+    }
+}
+
+/* --- CPU NTT path: the fair-speed CPU baseline for ring products (FLINT multiplies
+ * sub-quadratically).  Requires q prime, 2n | q-1.  Same results as the schoolbook. */
+static uint32_t find_primitive_2n_root(uint32_t n, uint32_t q) {
+    /* psi with psi^n = -1: smallest g^((q-1)/2n) over g=2,3,.. that has order exactly 2n */
+    uint64_t e = (uint64_t)(q - 1) / (2ull * n);
+    for (uint32_t g = 2; g < q; g++) {
+        uint32_t psi = powmod(g, e, q);
+        if (powmod(psi, n, q) == q - 1) return psi;
+    }
+    return 0;
+}
+uint32_t qfo_find_psi(uint32_t n, uint32_t q) {
+    if ((q - 1) % (2ull * n)) return 0;
+    return find_primitive_2n_root(n, q);
+}
+static uint32_t bitrev(uint32_t x, int bits) {
+    uint32_t r = 0;
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+}
+typedef struct { uint32_t n, q, ninv; uint32_t *psi_br, *ipsi_br; } qfo_ntt_plan;
+
+qfo_ntt_plan *qfo_ntt_plan_create(uint32_t n, uint32_t q) {
+    uint32_t psi = qfo_find_psi(n, q);
+    if (!psi) return NULL;
+    int lg = 0; while ((1u << lg) < n) lg++;
+    qfo_ntt_plan *p = (qfo_ntt_plan *)malloc(sizeof *p);
+    p->n = n; p->q = q; p->ninv = powmod(n % q, q - 2, q);
+    p->psi_br = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    p->ipsi_br = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    uint32_t ipsi = powmod(psi, q - 2, q);
+    for (uint32_t i = 0; i < n; i++) {
+        p->psi_br[i] = powmod(psi, bitrev(i, lg), q);
+        p->ipsi_br[i] = powmod(ipsi, bitrev(i, lg), q);
+    }
+    return p;
+}
+void qfo_ntt_plan_destroy(qfo_ntt_plan *p) { if (p) { free(p->psi_br); free(p->ipsi_br); free(p); } }
+
+/* forward negacyclic NTT, Cooley-Tukey, natural in -> bit-reversed out */
+void qfo_ntt_forward(const qfo_ntt_plan *p, uint32_t *a) {
+    uint32_t n = p->n, q = p->q;
+    for (uint32_t m = 1, t = n >> 1; m < n; m <<= 1, t >>= 1)
+        for (uint32_t i = 0; i < m; i++) {
+            uint32_t w = p->psi_br[m + i];
+            for (uint32_t j = 2 * i * t; j < 2 * i * t + t; j++) {
+                uint32_t u = a[j], v = mulmod(a[j + t], w, q);
+                a[j] = addmod(u, v, q);
+                a[j + t] = submod(u, v, q);
+            }
+        }
+}
+/* inverse, Gentleman-Sande, bit-reversed in -> natural out, scaled by n^-1 */
+void qfo_ntt_inverse(const qfo_ntt_plan *p, uint32_t *a) {
+    uint32_t n = p->n, q = p->q;
+    for (uint32_t m = n >> 1, t = 1; m >= 1; m >>= 1, t <<= 1)
+        for (uint32_t i = 0; i < m; i++) {
+            uint32_t w = p->ipsi_br[m + i];
+            for (uint32_t j = 2 * i * t; j < 2 * i * t + t; j++) {
+                uint32_t u = a[j], v = a[j + t];
+                a[j] = addmod(u, v, q);
+                a[j + t] = mulmod(submod(u, v, q), w, q);
+            }
+        }
+    for (uint32_t i = 0; i < n; i++) a[i] = mulmod(a[i], p->ninv, q);
+}
+void qfo_polymul_ntt(const qfo_ntt_plan *p, const uint32_t *a, const uint32_t *b, uint32_t *c) {
+    uint32_t n = p->n;
+    uint32_t *t = (uint32_t *)malloc(sizeof(uint32_t) * 2 * n);
+    memcpy(t, a, 4 * n); memcpy(t + n, b, 4 * n);
+    qfo_ntt_forward(p, t); qfo_ntt_forward(p, t + n);
+    for (uint32_t i = 0; i < n; i++) c[i] = mulmod(t[i], t[n + i], p->q);
+    qfo_ntt_inverse(p, c);
+    free(t);
+}
+/* batch of independent products c_i = a_i * b_i; use_ntt selects the
+ * CPU algorithm only -- results are identical. */
+int qfo_polymul_batch(const uint32_t *a, const uint32_t *b, uint32_t n, uint32_t q, uint64_t B,
+                      int use_ntt, uint32_t *c) {
+    if (!use_ntt) {
+        for (uint64_t i = 0; i < B; i++)
+            qfo_polymul_negacyclic(a + i * n, b + i * n, n, q, c + i * n);
+        return 0;
+    }
+    qfo_ntt_plan *p = qfo_ntt_plan_create(n, q);
+    if (!p) return -1;
+    for (uint64_t i = 0; i < B; i++) qfo_polymul_ntt(p, a + i * n, b + i * n, c + i * n);
+    qfo_ntt_plan_destroy(p);
+    return 0;
+}
+
+/* RingLPR::enc (ring_lpr.rs:422-461): u = a*r + e1 ; v = b*r + e2 + mu(X)*floor(q/2),
+ * mu bit i -> coefficient i (ring_lpr.rs:318-329), mu bits LSB-first packed, n bits/message. */
+void qfo_ringlpr_enc_batch(const uint32_t *a, const uint32_t *bpoly, uint32_t n, uint32_t q,
+                           const uint32_t *r, const uint32_t *e1, const uint32_t *e2,
+                           const uint8_t *mu_bits, uint64_t B, uint32_t *u, uint32_t *v) {
+    size_t mu_stride = (n + 7) / 8;
+    for (uint64_t i = 0; i < B; i++) {
+        qfo_polymul_negacyclic(a, r + i * n, n, q, u + i * n);
+        qfo_polymul_negacyclic(bpoly, r + i * n, n, q, v + i * n);
+        for (uint32_t k = 0; k < n; k++) {
+            u[i * n + k] = addmod(u[i * n + k], e1[i * n + k], q);
+            uint32_t t = addmod(v[i * n + k], e2[i * n + k], q);
+            if ((mu_bits[i * mu_stride + (k >> 3)] >> (k & 7)) & 1) t = addmod(t, q / 2, q);
+            v[i * n + k] = t;
+        }
+    }
+}
+/* RingLPR::dec (ring_lpr.rs:489-508): w = v - s*u ; bit_i = [dist(w_i,q/2) < dist(w_i,0)] */
+void qfo_ringlpr_dec_batch(const uint32_t *s, uint32_t n, uint32_t q, const uint32_t *u,
+                           const uint32_t *v, uint64_t B, uint8_t *mu_bits) {
+    size_t mu_stride = (n + 7) / 8;
+    uint32_t *w = (uint32_t *)malloc(4 * n);
+    memset(mu_bits, 0, B * mu_stride);
+    for (uint64_t i = 0; i < B; i++) {
+        qfo_polymul_negacyclic(s, u + i * n, n, q, w);
+        for (uint32_t k = 0; k < n; k++) {
+            uint32_t d = submod(v[i * n + k], w[k], q);
+            if (ring_dist(d, q / 2, q) < ring_dist(d, 0, q))
+                mu_bits[i * mu_stride + (k >> 3)] |= (uint8_t)(1u << (k & 7));
+        }
+    }
+    free(w);
+}
+
+/* PSFGPVRing::f_a + check_domain + FDH::vfy (gpv_ring.rs:235-239, 266-275, fdh.rs:115-123):
+ *   t = sum_j A_j * (sigma_j mod q) in R_q ; in_domain = [ sum sigma^2 <= norm_bound ]
+ *   ok = in_domain && t == u
+ * A: mbar polys (mbar = k+2), sigma: signed coefficients [B][mbar][n], u: [B][n].
+ * norm_bound = floor(s^2 * n*mbar) computed exactly by the caller.  t_out (optional) gets t. */
+void qfo_fdh_ring_verify_batch(const uint32_t *A, uint32_t mbar, uint32_t n, uint32_t q,
+                               const int32_t *sigma, const uint32_t *u, uint64_t norm_bound,
+                               uint64_t B, uint32_t *t_out, uint8_t *ok) {
+    uint32_t *sj = (uint32_t *)malloc(4 * n), *prod = (uint32_t *)malloc(4 * n),
+             *t = (uint32_t *)malloc(4 * n);
+    for (uint64_t b = 0; b < B; b++) {
+        u128 norm = 0;
+        memset(t, 0, 4 * n);
+        for (uint32_t j = 0; j < mbar; j++) {
+            const int32_t *sg = sigma + (b * mbar + j) * n;
+            for (uint32_t k = 0; k < n; k++) {
+                int64_t v = sg[k];
+                norm += (uint64_t)(v * v);
+                int64_t rr = v % (int64_t)q;
+                sj[k] = (uint32_t)(rr < 0 ? rr + q : rr);
+            }
+            qfo_polymul_negacyclic(A + (size_t)j * n, sj, n, q, prod);
+            for (uint32_t k = 0; k < n; k++) t[k] = addmod(t[k], prod[k], q);
+        }
+        int good = norm <= (u128)norm_bound;
+        for (uint32_t k = 0; k < n; k++) if (t[k] != u[b * n + k]) good = 0;
+        if (t_out) memcpy(t_out + b * n, t, 4 * n);
+        ok[b] = (uint8_t)good;
+    }
+    free(sj); free(prod); free(t);
+}
+
+/* ------------------------------------------------ SHA-256 hash-to-Z_q */
+
+static const uint32_t K256[64] = {
+    0x428a2f98,0x71374491,0xb5c0fbcf,0xe9b5dba5,0x3956c25b,0x59f111f1,0x923f82a4,0xab1c5ed5,
+    0xd807aa98,0x12835b01,0x243185be,0x550c7dc3,0x72be5d74,0x80deb1fe,0x9bdc06a7,0xc19bf174,
+    0xe49b69c1,0xefbe4786,0x0fc19dc6,0x240ca1cc,0x2de92c6f,0x4a7484aa,0x5cb0a9dc,0x76f988da,
+    0x983e5152,0xa831c66d,0xb00327c8,0xbf597fc7,0xc6e00bf3,0xd5a79147,0x06ca6351,0x14292967,
+    0x27b70a85,0x2e1b2138,0x4d2c6dfc,0x53380d13,0x650a7354,0x766a0abb,0x81c2c92e,0x92722c85,
+    0xa2bfe8a1,0xa81a664b,0xc24b8b70,0xc76c51a3,0xd192e819,0xd6990624,0xf40e3585,0x106aa070,
+    0x19a4c116,0x1e376c08,0x2748774c,0x34b0bcb5,0x391c0cb3,0x4ed8aa4a,0x5b9cca4f,0x682e6ff3,
+    0x748f82ee,0x78a5636f,0x84c87814,0x8cc70208,0x90befffa,0xa4506ceb,0xbef9a3f7,0xc67178f2};
+#define ROR(x, n) (((x) >> (n)) | ((x) << (32 - (n))))
+static void sha256_block(uint32_t h[8], const uint8_t *p) {
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++)
+        w[i] = (uint32_t)p[4*i] << 24 | (uint32_t)p[4*i+1] << 16 | (uint32_t)p[4*i+2] << 8 | p[4*i+3];
+    for (int i = 16; i < 64; i++) {
+        uint32_t s0 = ROR(w[i-15], 7) ^ ROR(w[i-15], 18) ^ (w[i-15] >> 3);
+        uint32_t s1 = ROR(w[i-2], 17) ^ ROR(w[i-2], 19) ^ (w[i-2] >> 10);
+        w[i] = w[i-16] + s0 + w[i-7] + s1;
+    }
+    uint32_t a=h[0],b=h[1],c=h[2],d=h[3],e=h[4],f=h[5],g=h[6],hh=h[7];
+    for (int i = 0; i < 64; i++) {
+        uint32_t S1 = ROR(e,6) ^ ROR(e,11) ^ ROR(e,25), ch = (e & f) ^ (~e & g);
+        uint32_t t1 = hh + S1 + ch + K256[i] + w[i];
+        uint32_t S0 = ROR(a,2) ^ ROR(a,13) ^ ROR(a,22), mj = (a & b) ^ (a & c) ^ (b & c);
+        uint32_t t2 = S0 + mj;
+        hh=g; g=f; f=e; e=d+t1; d=c; c=b; b=a; a=t1+t2;
+    }
+    h[0]+=a; h[1]+=b; h[2]+=c; h[3]+=d; h[4]+=e; h[5]+=f; h[6]+=g; h[7]+=hh;
+}
+void qfo_sha256(const uint8_t *msg, size_t len, uint8_t out[32]) {
+    uint32_t h[8] = {0x6a09e667,0xbb67ae85,0x3c6ef372,0xa54ff53a,0x510e527f,0x9b05688c,0x1f83d9ab,0x5be0cd19};
+    size_t i = 0;
+    for (; i + 64 <= len; i += 64) sha256_block(h, msg + i);
+    uint8_t tail[128] = {0};
+    size_t rem = len - i;
+    memcpy(tail, msg + i, rem);
+    tail[rem] = 0x80;
+    size_t tl = rem + 1 + 8 <= 64 ? 64 : 128;
+    uint64_t bits = (uint64_t)len * 8;
+    for (int k = 0; k < 8; k++) tail[tl - 1 - k] = (uint8_t)(bits >> (8 * k));
+    sha256_block(h, tail);
+    if (tl == 128) sha256_block(h, tail + 64);
+    for (int k = 0; k < 8; k++) { out[4*k]=(uint8_t)(h[k]>>24); out[4*k+1]=(uint8_t)(h[k]>>16); out[4*k+2]=(uint8_t)(h[k]>>8); out[4*k+3]=(uint8_t)h[k]; }
+}
+/* hash_to_zq_sha256 (sha256.rs:65-83): for i in 0..=bits(q)/128, digest_i = sha256("{i} {q} {string}");
+ * the lowercase-hex digests are concatenated in i order and parsed base 16 -> one big integer mod q. */
+uint32_t qfo_hash_to_zq(const char *str, size_t len, uint32_t q) {
+    int bits = 0; for (uint32_t t = q; t; t >>= 1) bits++;
+    uint32_t acc = 0;
+    char *buf = (char *)malloc(len + 64);
+    for (int i = 0; i <= bits / 128; i++) {
+        int pre = sprintf(buf, "%d %u ", i, q);
+        memcpy(buf + pre, str, len);
+        uint8_t d[32];
+        qfo_sha256((const uint8_t *)buf, pre + len, d);
+        for (int k = 0; k < 32; k++) acc = (uint32_t)((((uint64_t)acc << 8) | d[k]) % q);
+    }
+    free(buf);
+    return acc;
+}
+/* hash_to_mat_zq_sha256 (sha256.rs:110-133): entry (i,j) = hash_to_zq("{i} {j} {rows} {cols} {string}") */
+void qfo_hash_to_mat_zq(const char *str, size_t len, uint32_t rows, uint32_t cols, uint32_t q,
+                        uint32_t *out /* row-major */) {
+    char *buf = (char *)malloc(len + 96);
+    for (uint32_t i = 0; i < rows; i++)
+        for (uint32_t j = 0; j < cols; j++) {
+            int pre = sprintf(buf, "%u %u %u %u ", i, j, rows, cols);
+            memcpy(buf + pre, str, len);
+            out[(size_t)i * cols + j] = qfo_hash_to_zq(buf, pre + len, q);
+        }
+    free(buf);
+}
+
+/* ------------------------------------------------ reference-shaped single-message cycle
+ * Mirrors benches/regev.rs:15-22 (gen, enc, dec of one bit) with the seeded generator in
+ * place of the reference's unseeded samplers; one mat-vec per operator, fresh buffers per
+ * call -- the call structure of the reference.  Returns the decrypted bit. */
+uint32_t qfo_regev_cycle(uint32_t n, uint32_t m, uint32_t q, uint32_t W, uint64_t seed,
+                         uint32_t msg) {
+    uint32_t *A = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n + 1) * m);
+    uint32_t *s = (uint32_t *)malloc(4 * n), *e = (uint32_t *)malloc(4 * m);
+    uint32_t *x = (uint32_t *)malloc(4 * m), *c = (uint32_t *)malloc(4 * (n + 1));
+    /* gen (regev.rs:350-374) */
+    qfo_sample_uniform(seed, 1, 0, (uint64_t)n * m, q, A);
+    qfo_sample_uniform(seed, 2, 0, n, q, s);
+    qfo_sample_noise(seed, 4, 0, m, q, W, e);
+    qfo_vecmat(A, n, m, q, s, A + (size_t)n * m);
+    for (uint32_t j = 0; j < m; j++) A[(size_t)n * m + j] = addmod(A[(size_t)n * m + j], e[j], q);
+    /* enc (regev.rs:396-414) */
+    for (uint32_t j = 0; j < m; j++) x[j] = (uint32_t)(qfo_rand64(seed, 3, j) & 1);
+    qfo_matvec(A, n + 1, m, q, x, c);
+    if (msg & 1) c[n] = addmod(c[n], q / 2, q);
+    /* dec (regev.rs:438-452) */
+    uint8_t bit;
+    qfo_dot_decode_batch(s, n, q, c, 1, &bit);
+    free(A); free(s); free(e); free(x); free(c);
+    return bit;
+}

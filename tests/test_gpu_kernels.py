@@ -1,0 +1,148 @@
+"""GPU parity tests proper: every kernel, called through the C ABI, against the CPU oracle
+(oracle/qf_oracle.c) on the same seeded inputs.  Bit-exact -- this is integer work."""
+import numpy as np
+import pytest
+
+from oracle import coracle as co
+from crypto_amd.device import X_BITS, X_I32, X_U32, bit_stride, pack_bits
+
+pytestmark = pytest.mark.gpu
+SEED = 0x5146414C4C
+
+
+def test_sampler_matches_oracle(ctx):
+    q = 1073741789
+    d = ctx.to_host_u32(ctx.sample_uniform(SEED, 1, 5, 4099, q))
+    assert np.array_equal(d, co.sample_uniform(SEED, 1, 5, 4099, q))
+    d = ctx.to_host_u32(ctx.sample_noise(SEED, 4, 7, 3001, q, 4096))
+    assert np.array_equal(d, co.sample_noise(SEED, 4, 7, 3001, q, 4096))
+    st = bit_stride(867)
+    d = ctx.to_host_u8(ctx.sample_bits(SEED, 3, 11, 37, 867, st))
+    assert np.array_equal(d, co.sample_bits(SEED, 3, 11, 37, 867, st))
+
+
+@pytest.mark.parametrize("rows,cols,q", [(14, 154, 1427), (51, 867, 124991), (257, 6168, 16777213),
+                                          (1, 3, 7), (33, 4097, 1073741789), (5, 18, 11)])
+def test_matvec_vecmat(ctx, rows, cols, q):
+    A = co.sample_uniform(SEED, 1, 0, rows * cols, q).reshape(rows, cols)
+    key = ctx.key_upload(A, q)
+    x = co.sample_uniform(SEED, 6, 0, cols, q)
+    assert np.array_equal(ctx.matvec(key, x), co.matvec(A, x, q))
+    s = co.sample_uniform(SEED, 2, 0, rows, q)
+    assert np.array_equal(ctx.vecmat(key, s), co.vecmat(s, A, q))
+
+
+@pytest.mark.parametrize("n,m,q,B", [(13, 154, 1427, 70), (50, 867, 124991, 300), (256, 6168, 16777213, 513),
+                                     (3, 16, 13, 5), (64, 1000, 2147483629, 40), (31, 129, 251, 33)])
+def test_matmul_bits_regev_shape(ctx, n, m, q, B):
+    """Regev::enc batched (regev.rs:396-414): pk*x + message in the last entry."""
+    pk = co.sample_uniform(SEED, 1, 0, (n + 1) * m, q).reshape(n + 1, m)
+    st = bit_stride(m)
+    xb = co.sample_bits(SEED, 3, 0, B, m, st)
+    msg = (co.sample_uniform(SEED, 5, 0, B, 2)).astype(np.uint8)
+    key = ctx.key_upload(pk, q)
+    out = ctx.matmul(key, ctx.to_dev_u8(xb), X_BITS, B, msg=ctx.to_dev_u8(msg))
+    ref = co.matmul_batch(pk, q, xb, co.X_BITS, B, msg=msg)
+    assert np.array_equal(ctx.to_host_u32(out), ref)
+
+
+@pytest.mark.parametrize("n,q,W,B,digits", [(10, 983, 3, 50, 0), (10, 983, 3, 50, 1), (64, 1073741789, 2000, 70, 3),
+                                            (64, 1073741789, 2000, 70, 2), (40, 65521, 30000, 35, 1), (128, 8380417, 100, 64, 0)])
+def test_matmul_u32_lpr_shape(ctx, n, q, W, B, digits):
+    """LPR::enc batched (lpr.rs:394-430): pk*r + e + message; digits = caller's width promise
+    (a broken promise must fall back to full width and stay exact)."""
+    pk = co.sample_uniform(SEED, 1, 0, (n + 1) * n, q).reshape(n + 1, n)
+    r = co.sample_noise(SEED, 3, 0, B * n, q, W).reshape(B, n)
+    e = co.sample_noise(SEED, 4, 0, B * (n + 1), q, W).reshape(B, n + 1)
+    msg = (co.sample_uniform(SEED, 5, 0, B, 2)).astype(np.uint8)
+    key = ctx.key_upload(pk, q)
+    out = ctx.matmul(key, ctx.to_dev_u32(r), X_U32, B, addend=ctx.to_dev_u32(e), msg=ctx.to_dev_u8(msg), x_digits=digits)
+    ref = co.matmul_batch(pk, q, r, co.X_U32, B, addend=e, msg=msg)
+    assert np.array_equal(ctx.to_host_u32(out), ref)
+
+
+def test_matmul_full_width_and_i32(ctx):
+    """SIS hash of uniform Z_q vectors (sis.rs:46,161-167) and a signed operand."""
+    n, m, q, B = 32, 300, 8380417, 90
+    A = co.sample_uniform(SEED, 1, 0, n * m, q).reshape(n, m)
+    v = co.sample_uniform(SEED, 6, 0, B * m, q).reshape(B, m)
+    key = ctx.key_upload(A, q)
+    out = ctx.matmul(key, ctx.to_dev_u32(v), X_U32, B)
+    assert np.array_equal(ctx.to_host_u32(out), co.matmul_batch(A, q, v, co.X_U32, B))
+    sg = (co.sample_uniform(SEED, 7, 0, B * m, 2001).astype(np.int64) - 1000).astype(np.int32).reshape(B, m)
+    out = ctx.matmul(key, ctx.to_dev_i32(sg), X_I32, B, x_digits=2)
+    assert np.array_equal(ctx.to_host_u32(out), co.matmul_batch(A, q, sg, co.X_I32, B))
+
+
+def test_matmul_transposed_key_dual_regev(ctx):
+    """DualRegev::enc (dual_regev.rs:385-413): c^t = s^t*pk + e^t, key uploaded transposed."""
+    n, m, q, B = 20, 270, 7993, 45
+    pk = co.sample_uniform(SEED, 1, 0, n * (m + 1), q).reshape(n, m + 1)
+    s = co.sample_uniform(SEED, 2, 0, B * n, q).reshape(B, n)
+    e = co.sample_noise(SEED, 4, 0, B * (m + 1), q, 5).reshape(B, m + 1)
+    msg = (co.sample_uniform(SEED, 5, 0, B, 2)).astype(np.uint8)
+    key = ctx.key_upload(pk, q, transpose=True)
+    assert (key.rows, key.cols) == (m + 1, n)
+    out = ctx.to_host_u32(ctx.matmul(key, ctx.to_dev_u32(s), X_U32, B, addend=ctx.to_dev_u32(e), msg=ctx.to_dev_u8(msg)))
+    ref = co.matmul_batch(np.ascontiguousarray(pk.T), q, s, co.X_U32, B, addend=e, msg=msg)
+    assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("n,q,B", [(13, 1427, 100), (256, 16777213, 1000), (1024, 1073741789, 77)])
+def test_dot_decode(ctx, n, q, B):
+    s = co.sample_uniform(SEED, 2, 0, n, q)
+    Cm = co.sample_uniform(SEED, 9, 0, B * (n + 1), q).reshape(B, n + 1)
+    w = ((q - s.astype(np.int64)) % q).astype(np.uint32)
+    bits = ctx.to_host_u8(ctx.dot_decode(ctx.to_dev_u32(w), q, ctx.to_dev_u32(Cm)))
+    assert np.array_equal(bits, co.dot_decode_batch(s, q, Cm))
+
+
+@pytest.mark.parametrize("n,q,B", [(1024, 1073479681, 37), (16, 2399, 50), (4, 16, 9), (64, 257, 70), (512, 92897729, 6),
+                                   (2, 5, 300), (2048, 1073479681, 3), (256, 7681, 20)])
+def test_polymul(ctx, n, q, B):
+    a = co.sample_uniform(SEED, 6, 0, B * n, q).reshape(B, n)
+    b = co.sample_uniform(SEED, 6, B * n, B * n, q).reshape(B, n)
+    ring = ctx.ring(n, q)
+    c = ctx.to_host_u32(ring.polymul(ctx.to_dev_u32(a), ctx.to_dev_u32(b)))
+    assert np.array_equal(c, co.polymul_batch(a, b, q))
+
+
+@pytest.mark.parametrize("n,q,W,B", [(1024, 1073479681, 2900, 21), (16, 2399, 4, 64), (64, 257 * 512 + 1, 3, 33), (512, 92897729, 200, 5)])
+def test_ringlpr_enc_dec(ctx, n, q, W, B):
+    a = co.sample_uniform(SEED, 1, 0, n, q)
+    s = co.sample_noise(SEED, 2, 0, n, q, W)
+    e = co.sample_noise(SEED, 4, 0, n, q, W)
+    bpoly = (co.polymul_batch(a[None], s[None], q)[0].astype(np.int64) + e) % q
+    r = co.sample_noise(SEED, 3, 0, B * n, q, W).reshape(B, n)
+    e1 = co.sample_noise(SEED, 4, n, B * n, q, W).reshape(B, n)
+    e2 = co.sample_noise(SEED, 4, n + B * n, B * n, q, W).reshape(B, n)
+    mu = co.sample_bits(SEED, 5, 0, B, n, (n + 7) // 8)
+    ring = ctx.ring(n, q)
+    pk = ring.key(np.stack([a, bpoly.astype(np.uint32)]))
+    sk = ring.key(s[None])
+    u, v = ring.ringlpr_enc(pk, ctx.to_dev_u32(r), ctx.to_dev_u32(e1), ctx.to_dev_u32(e2), ctx.to_dev_u8(mu))
+    ur, vr = co.ringlpr_enc_batch(a, bpoly, q, r, e1, e2, mu)
+    assert np.array_equal(ctx.to_host_u32(u), ur) and np.array_equal(ctx.to_host_u32(v), vr)
+    dec = ctx.to_host_u8(ring.ringlpr_dec(sk, u, v))
+    assert np.array_equal(dec, co.ringlpr_dec_batch(s, q, ur, vr))
+
+
+@pytest.mark.parametrize("n,q,B", [(1024, 1073479681, 5), (8, 512, 40), (64, 257, 17)])
+def test_fdh_ring_verify(ctx, n, q, B):
+    k = (q - 1).bit_length()
+    mbar = k + 2
+    A = co.sample_uniform(SEED, 1, 0, mbar * n, q).reshape(mbar, n)
+    A[0] = 0; A[0, 0] = 1
+    sigma = (co.sample_uniform(SEED, 7, 0, B * mbar * n, 201).astype(np.int64) - 100).astype(np.int32).reshape(B, mbar, n)
+    bound = int((sigma[0].astype(np.int64) ** 2).sum()) + 50
+    zero_u = np.zeros((B, n), np.uint32)
+    t_ref, _ = co.fdh_ring_verify_batch(A, q, sigma, zero_u, bound)
+    u = t_ref.copy()
+    u[1, 3] = (u[1, 3] + 1) % q          # wrong target -> reject
+    ring = ctx.ring(n, q)
+    ak = ring.key(A)
+    ok, t = ring.fdh_verify(ak, ctx.to_dev_i32(sigma), ctx.to_dev_u32(u), bound, want_t=True)
+    t_ref, ok_ref = co.fdh_ring_verify_batch(A, q, sigma, u, bound)
+    assert np.array_equal(ctx.to_host_u32(t), t_ref)
+    assert np.array_equal(ctx.to_host_u8(ok), ok_ref)
+    assert ok_ref[1] == 0 and ok_ref[0] == 1
