@@ -1,0 +1,48 @@
+"""Shared plumbing of the three matrix schemes (Regev, DualRegev, LPR): device key caching,
+single-message products on kernel (c), batched products on kernel (a), batched decryption."""
+from __future__ import annotations
+
+import numpy as np
+
+from ...device import X_BITS, X_U32, bit_stride, pack_bits
+from ...math import MatZ, MatZq
+from ...runtime import Randomness, default_context
+
+
+class MatrixSchemeMixin:
+    def _init_runtime(self, ctx=None, seed=None):
+        self._ctx = ctx
+        self.rng = Randomness(seed, ctx) if seed is not None else Randomness(ctx=ctx)
+
+    @property
+    def ctx(self):
+        return self._ctx or default_context()
+
+    def _dev_key(self, mat: MatZq, transpose: bool = False):
+        """Upload (once) and cache the digit planes of a public matrix."""
+        tag = (id(self.ctx), transpose)
+        key = mat._dev.get(tag)
+        if key is None or key.h is None:
+            key = self.ctx.key_upload(mat.entries, mat.q, transpose=transpose)
+            mat._dev[tag] = key
+        return key
+
+    def _check_pk(self, pk: MatZq, rows: int, cols: int):
+        # the reference panics on mismatching dimensions / moduli inside qfall-math
+        if not isinstance(pk, MatZq):
+            raise TypeError("public key must be a MatZq")
+        if pk.q != self.q:
+            raise ValueError("mismatching modulus between scheme and key")
+        if pk.entries.shape != (rows, cols):
+            raise ValueError(f"mismatching matrix dimensions: expected {rows}x{cols}, got {pk.entries.shape}")
+
+    def _decode_batch(self, w: np.ndarray, ciphers) -> np.ndarray:
+        """bits = decision rule applied to <w, c[:-1]> + c[-1] for each row of `ciphers`."""
+        c = ciphers if not isinstance(ciphers, np.ndarray) else self.ctx.to_dev_u32(ciphers)
+        bits = self.ctx.dot_decode(self.ctx.to_dev_u32(w), self.q, c)
+        return self.ctx.to_host_u8(bits)
+
+
+def message_bit(message) -> int:
+    """message.modulo(2): Euclidean remainder, also for negative values (regev.rs:398,598-612)."""
+    return int(message) % 2

@@ -1,0 +1,66 @@
+"""Process-wide default device context and the seeded randomness the scheme layer draws from.
+
+The reference samples from an unseeded RNG at every call (e.g. regev.rs:352-364,401).  Here the
+scheme objects own a `Randomness` (master seed + per-stream counters over the SplitMix64
+counter-mode generator of include/qfgpu.h), so that every run -- GPU path and CPU oracle alike
+-- consumes the same inputs.  Streams: 1 uniform A / a, 2 secret, 3 x / r, 4 noise e,
+5 messages, 6 free operands.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+MASTER_SEED = 0x5146414C4C  # "QFALL"
+
+_default_ctx = None
+
+
+def default_context():
+    """Lazily created Context on the current HIP device (no CPU fallback)."""
+    global _default_ctx
+    if _default_ctx is None:
+        import torch
+        from .device import Context
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        _default_ctx = Context(dev)
+    return _default_ctx
+
+
+def set_default_context(ctx):
+    global _default_ctx
+    _default_ctx = ctx
+
+
+class Randomness:
+    """Counter-mode draws; each stream advances its own counter so draws never overlap."""
+
+    def __init__(self, seed: int = MASTER_SEED, ctx=None):
+        self.seed = int(seed)
+        self._ctx = ctx
+        self.pos = {}
+
+    @property
+    def ctx(self):
+        return self._ctx or default_context()
+
+    def _take(self, stream: int, count: int) -> int:
+        first = self.pos.get(stream, 0)
+        self.pos[stream] = first + count
+        return first
+
+    def uniform(self, stream: int, count: int, q: int) -> np.ndarray:
+        first = self._take(stream, count)
+        return self.ctx.to_host_u32(self.ctx.sample_uniform(self.seed, stream, first, count, q))
+
+    def noise(self, stream: int, count: int, q: int, W: int) -> np.ndarray:
+        first = self._take(stream, count)
+        return self.ctx.to_host_u32(self.ctx.sample_noise(self.seed, stream, first, count, q, W))
+
+    def bits(self, stream: int, count: int) -> np.ndarray:
+        """count independent bits as a 0/1 uint32 vector (MatZ::sample_uniform(m,1,0,2))."""
+        from .device import unpack_bits
+        first = self._take(stream, 1)  # one generator row per call
+        packed = self.ctx.to_host_u8(self.ctx.sample_bits(self.seed, stream, first, 1, count))
+        return unpack_bits(packed, count)[0].astype(np.uint32)

@@ -1,0 +1,223 @@
+"""GPU: scheme-level tests that read like the reference's own (#[cfg(test)] modules cited per
+test), driven through the Python mirror of the trait API; every ciphertext / digest is also
+compared bit for bit with the CPU oracle on the same seeded randomness."""
+import numpy as np
+import pytest
+
+from oracle import coracle as co
+from oracle import pyoracle as po
+from crypto_amd.construction.pk_encryption import LPR, DualRegev, Regev, RingLPR
+from crypto_amd.construction.hash import SISHash
+from crypto_amd.construction.signature import FDH
+from crypto_amd.math import MatPolyOverZ, MatZq
+from crypto_amd.primitive.psf import GadgetParametersRing, PSFGPVRing
+from crypto_amd.device import QfError, unpack_bits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("make", [Regev.default, lambda **k: Regev.new_from_n(50, **k),
+                                  LPR.default, lambda **k: LPR.new_from_n(50, **k),
+                                  DualRegev.default, lambda **k: DualRegev.new_from_n(20, **k)])
+def test_cycle_zero_and_one(ctx, make):
+    """regev.rs:547-595, dual_regev.rs:545-593, lpr.rs:564-616: gen -> enc -> dec == msg."""
+    scheme = make(ctx=ctx)
+    pk, sk = scheme.gen()
+    for msg in (0, 1, 0, 1):
+        assert scheme.dec(sk, scheme.enc(pk, msg)) == msg
+
+
+def test_regev_modulo_two_semantics(ctx):
+    """regev.rs:598-612: the message is reduced mod 2, also for i64::MAX / i64::MIN."""
+    r = Regev.default(ctx=ctx)
+    pk, sk = r.gen()
+    assert r.dec(sk, r.enc(pk, 2 ** 63 - 1)) == 1
+    assert r.dec(sk, r.enc(pk, -(2 ** 63))) == 0
+    assert r.dec(sk, r.enc(pk, 3)) == 1
+
+
+@pytest.mark.parametrize("cls", [Regev, LPR, DualRegev])
+def test_multi_bit(ctx, cls):
+    """regev.rs:622-669: LSB-first multi-bit encryption of |message|."""
+    s = cls.default(ctx=ctx)
+    pk, sk = s.gen()
+    for msg in (15, 3, 0, 255, -9):
+        assert s.dec_multiple_bits(sk, s.enc_multiple_bits(pk, msg)) == abs(msg)
+
+
+def test_regev_single_and_batch_agree_with_oracle(ctx):
+    r = Regev.new_from_n(20, ctx=ctx)
+    pk, sk = r.gen()
+    x = r.rng.bits(3, r.m)
+    c = r.enc(pk, 1, x=x)
+    assert c.entries[:, 0].tolist() == po.regev_enc(pk.entries.tolist(), x.tolist(), 1, r.q)
+    B = 70
+    msgs = np.arange(B) % 2
+    xb = co.sample_bits(7, 3, 0, B, r.m, ((r.m + 127) // 128) * 16)
+    cb = ctx.to_host_u32(r.enc_batch(pk, msgs, x_bits=xb))
+    assert np.array_equal(cb, co.matmul_batch(pk.entries, r.q, xb, co.X_BITS, B, msg=msgs.astype(np.uint8)))
+    assert r.dec_batch(sk, cb).tolist() == msgs.tolist()
+    assert r.dec_batch(sk, cb).tolist() == co.dot_decode_batch(sk.entries[:, 0], r.q, cb).tolist()
+
+
+def test_lpr_batch_round_trip_and_oracle(ctx):
+    l = LPR.new_from_n(64, ctx=ctx)
+    pk, sk = l.gen()
+    B = 100
+    msgs = (np.arange(B) * 7 // 3) % 2
+    W = l.noise_width
+    rr = co.sample_noise(9, 3, 0, B * l.n, l.q, W).reshape(B, l.n)
+    ee = co.sample_noise(9, 4, 0, B * (l.n + 1), l.q, W).reshape(B, l.n + 1)
+    c = ctx.to_host_u32(l.enc_batch(pk, msgs, r=rr, e=ee))
+    assert np.array_equal(c, co.matmul_batch(pk.entries, l.q, rr, co.X_U32, B, addend=ee, msg=msgs.astype(np.uint8)))
+    assert l.dec_batch(sk, c).tolist() == msgs.tolist()
+    c2 = l.enc_batch(pk, msgs)                     # device-generated randomness
+    assert l.dec_batch(sk, c2).tolist() == msgs.tolist()
+
+
+def test_dual_regev_batch_round_trip_and_oracle(ctx):
+    d = DualRegev.new_from_n(16, ctx=ctx)
+    pk, sk = d.gen()
+    B = 40
+    msgs = np.arange(B) % 2
+    ss = co.sample_uniform(9, 3, 0, B * d.n, d.q).reshape(B, d.n)
+    ee = co.sample_noise(9, 4, 0, B * (d.m + 1), d.q, d.noise_width).reshape(B, d.m + 1)
+    c = ctx.to_host_u32(d.enc_batch(pk, msgs, s=ss, e=ee))
+    ref = co.matmul_batch(np.ascontiguousarray(pk.entries.T), d.q, ss, co.X_U32, B, addend=ee, msg=msgs.astype(np.uint8))
+    assert np.array_equal(c, ref)
+    assert d.dec_batch(sk, c).tolist() == msgs.tolist()
+    assert d.dec_batch(sk, c).tolist() == co.dualregev_decode_batch(sk.entries[:, 0], d.q, c).tolist()
+
+
+def test_key_dimension_and_modulus_mismatch_panic(ctx):
+    """qfall-math panics on mismatching dimensions / moduli; we raise."""
+    r = Regev.default(ctx=ctx)
+    pk, _ = r.gen()
+    with pytest.raises(ValueError):
+        Regev(13, 150, 1427, 0.01, ctx=ctx).enc(pk, 1)
+    with pytest.raises(ValueError):
+        Regev(13, 154, 1429, 0.01, ctx=ctx).enc(pk, 1)
+    key = ctx.key_upload(pk.entries, r.q)
+    with pytest.raises(QfError):
+        ctx.matvec(key, np.zeros(10, np.uint32))
+    with pytest.raises(QfError):
+        ctx.key_upload(pk.entries, 2 ** 31)          # q >= 2^31
+    with pytest.raises(QfError):
+        ctx.key_upload(pk.entries, 1)
+    # empty batch: no launch, empty result
+    out = ctx.matmul(key, ctx.empty_u8(0, 32), 0, 0)
+    assert tuple(out.shape) == (0, 14)
+
+
+@pytest.mark.parametrize("make,messages", [
+    (RingLPR.default, [0, 1, 2, 15, 212, 65535, 255, 13]),                 # ring_lpr.rs:608-630 (n=16)
+    (lambda **k: RingLPR.new_from_n(64, **k), [0, 1, 2 ** 63 - 1, 2 ** 64 - 1, 12345678901234567])])  # :633-652
+def test_ring_lpr_cycle(ctx, make, messages):
+    s = make(ctx=ctx)
+    pk, sk = s.gen()
+    for m in messages:
+        assert s.dec(sk, s.enc(pk, m)) == m
+    u, v = s.enc_batch(pk, messages)
+    assert s.dec_batch(sk, u, v) == messages
+
+
+def test_ring_lpr_message_wraps_mod_2n(ctx):
+    """ring_lpr.rs:655-667: enc(65536) at n=16 decrypts to 0."""
+    s = RingLPR.default(ctx=ctx)
+    pk, sk = s.gen()
+    assert s.dec(sk, s.enc(pk, 65536)) == 0
+    assert s.dec(sk, s.enc(pk, -3)) == 3
+
+
+def test_ring_lpr_n1024_ntt_friendly(ctx):
+    """BASELINE config 5: n=1024, q = 2^30 - 2^18 + 1."""
+    s = RingLPR(1024, 1073479681, 1 / (5 * 32 * 1000), ctx=ctx)
+    assert s.ring.uses_ntt
+    pk, sk = s.gen()
+    msgs = [0, 1, 2 ** 1024 - 1, 3 ** 600, 2 ** 1023 + 12345]
+    u, v = s.enc_batch(pk, msgs)
+    assert s.dec_batch(sk, u, v) == [m % 2 ** 1024 for m in msgs]
+    ur, vr = co.ringlpr_enc_batch(pk[0].coeffs, pk[1].coeffs, s.q_int,
+                                  co.sample_noise(s.rng.seed, 3, 0, 5 * 1024, s.q_int, s.noise_width).reshape(5, 1024),
+                                  co.sample_noise(s.rng.seed, 4, 1024, 5 * 1024, s.q_int, s.noise_width).reshape(5, 1024),
+                                  co.sample_noise(s.rng.seed, 4, 6 * 1024, 5 * 1024, s.q_int, s.noise_width).reshape(5, 1024),
+                                  np.stack([s.mu_bits(m) for m in msgs]))
+    assert np.array_equal(ctx.to_host_u32(u), ur) and np.array_equal(ctx.to_host_u32(v), vr)
+
+
+def test_sis_hash(ctx):
+    """sis.rs:237-278: dimensions and panics; digest compared with the oracle."""
+    h = SISHash.gen(5, 18, 11, ctx=ctx)
+    h.check_security()
+    v = MatZq(co.sample_uniform(3, 6, 0, 18, 11)[:, None], 11)
+    d = h.hash(v)
+    assert d.get_num_rows() == 5 and d.get_num_columns() == 1 and d.q == 11
+    assert d.entries[:, 0].tolist() == po.matvec(h.key.entries.tolist(), v.entries[:, 0].tolist(), 11)
+    with pytest.raises(ValueError):
+        h.hash(MatZq(np.zeros((1, 18), np.uint32), 11))       # row vector
+    with pytest.raises(ValueError):
+        h.hash(MatZq(np.zeros((17, 1), np.uint32), 11))       # wrong length
+    with pytest.raises(ValueError):
+        h.hash(MatZq(np.zeros((18, 1), np.uint32), 13))       # wrong modulus
+    h2 = SISHash.gen(32, 32 * 23, 8380417, ctx=ctx)
+    vals = co.sample_uniform(3, 6, 0, 50 * 736, 8380417).reshape(50, 736)
+    assert np.array_equal(ctx.to_host_u32(h2.hash_batch(vals)), co.matmul_batch(h2.key.entries, 8380417, vals, co.X_U32, 50))
+    bits = co.sample_bits(3, 3, 0, 50, 736, 96)
+    assert np.array_equal(ctx.to_host_u32(h2.hash_batch(bits, binary=True)), co.matmul_batch(h2.key.entries, 8380417, bits, co.X_BITS, 50))
+
+
+def test_psf_f_a_fixed_trapdoor_kat(ctx):
+    """gadget_ring.rs:189-210 with the fixed trapdoor of short_basis_ring.rs:357-378:
+    f_a(a, [e_i; r_i; unit_i]) == 2^i  in Z_16[X]/(X^4+1)."""
+    a = [[1, 0, 0, 0], [2, 8, 8, 12], [11, 10, 7, 13], [9, 6, 6, 12], [6, 11, 1, 6], [3, 10, 2, 9]]
+    r = [[-1, 7, 6, -8], [0, -2, 4], [0, 3, -4, 1], [6, 4, -1, 3]]
+    e = [[-4, 8, -3, 7], [1, -2, 2, 4], [-6, 7, -5], [-7, 10, -12, -15]]
+    psf = PSFGPVRing(GadgetParametersRing.init_default(4, 16), 1000, ctx=ctx)
+    assert psf.mbar == 6
+    sig = [MatPolyOverZ([e[i], r[i]] + [[1] if j == i else [] for j in range(4)], 4) for i in range(4)]
+    t = psf.f_a_batch(a, sig)
+    assert t.tolist() == [[1, 0, 0, 0], [2, 0, 0, 0], [4, 0, 0, 0], [8, 0, 0, 0]]
+
+
+def test_psf_check_domain(ctx):
+    """psf/gpv_ring.rs:347-437: shape and norm conditions."""
+    psf = PSFGPVRing(GadgetParametersRing.init_default(8, 512), 3, ctx=ctx)
+    n, mbar = 8, psf.mbar
+    bound = psf.norm_bound()                                   # 9 * 88 = 792
+    ok = MatPolyOverZ([[3] * n] * mbar, n)                     # norm^2 = 9*88 = 792 -> inside (<=)
+    assert psf.check_domain(ok)
+    too_long = MatPolyOverZ([[3] * n] * (mbar - 1) + [[3] * (n - 1) + [4]], n)   # 799 > 792
+    assert not psf.check_domain(too_long)
+    assert not psf.check_domain(MatPolyOverZ([[1] * n] * (mbar - 1), n))         # wrong length
+    assert bound == 792
+
+
+def test_fdh_ring_vfy(ctx):
+    """signature/fdh.rs:115-123 + fdh/gpv_ring.rs:99-123 (N=8, q=512): a valid preimage verifies,
+    a tampered one, a wrong message and an out-of-domain one do not.  (Preimages are built by
+    solving for sigma_0 since a_0 = 1; the trapdoor sampler is out of scope.)"""
+    n, q = 8, 512
+    fdh = FDH.init_gpv_ring(n, q, 10 ** 4, ctx=ctx)
+    mbar = fdh.psf.mbar
+    pk = co.sample_uniform(5, 1, 0, mbar * n, q).reshape(mbar, n)
+    pk[0] = 0; pk[0, 0] = 1
+    msgs = [f"Hello World! {i}" for i in range(10)]
+    sigs = []
+    for i, m in enumerate(msgs):
+        tail = (co.sample_uniform(5, 7, i * 1000, (mbar - 1) * n, 7).astype(np.int64) - 3).reshape(mbar - 1, n)
+        part = po.fdh_ring_f_a(pk[1:].tolist(), tail.tolist(), q)
+        u = po.hash_to_ring(m, n, q)
+        s0 = [((u[k] - part[k] + q // 2) % q) - q // 2 for k in range(n)]
+        sigs.append(MatPolyOverZ([s0] + tail.tolist(), n))
+    assert fdh.vfy_batch(msgs, sigs, pk) == [True] * 10
+    assert fdh.vfy(msgs[0], sigs[0], pk)
+    assert not fdh.vfy(msgs[0], sigs[1], pk)                       # signature of another message
+    bad = MatPolyOverZ(sigs[2].entries.copy(), n); bad.entries[3, 1] += 1
+    assert not fdh.vfy(msgs[2], bad, pk)
+    small = FDH.init_gpv_ring(n, q, 1, ctx=ctx)                    # s = 1: every sigma is too long
+    assert not small.vfy(msgs[0], sigs[0], pk)
+    # oracle agreement incl. t
+    u_all = np.array([po.hash_to_ring(m, n, q) for m in msgs], np.uint32)
+    sg = np.stack([s.entries for s in sigs]).astype(np.int32)
+    _, ok_ref = co.fdh_ring_verify_batch(pk, q, sg, u_all, fdh.psf.norm_bound())
+    assert ok_ref.tolist() == [1] * 10

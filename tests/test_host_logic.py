@@ -1,0 +1,146 @@
+"""CPU: host-side logic that needs no GPU -- the C ABI library loads and exports every symbol
+include/qfgpu.h declares, parameter generation follows the reference's shape rules, value types
+parse/print the qfall text formats."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from crypto_amd import _lib
+from crypto_amd.math import MatPolyOverZ, MatZ, MatZq, MathError, format_poly, gaussian_width, is_prime, parse_poly
+from crypto_amd.construction.pk_encryption import LPR, DualRegev, Regev, RingLPR
+from crypto_amd.construction.hash.sha256 import hash_to_mat_zq_sha256, hash_to_zq_sha256, sha256
+from crypto_amd.construction.hash import SISHash
+from crypto_amd.primitive.psf import GadgetParametersRing, PSFGPVRing
+from crypto_amd.utils import new_anticyclic, new_cyclic, rot_minus, rot_minus_matrix
+from crypto_amd.device import bit_stride, pack_bits, unpack_bits
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()  # raises if the .so is missing or lacks a symbol listed in _lib.SYMBOLS
+    header = open(os.path.join(ROOT, "include", "qfgpu.h")).read()
+    declared = set(re.findall(r"\b(qf_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.qf_version().startswith(b"qfgpu")
+
+
+def test_no_product_module_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "crypto_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("no CPU fallback", "") or "import oracle" not in src and "from oracle" not in src, f
+                assert "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_regev_parameter_rules():
+    """regev.rs:174-201, 229-295 and Appendix A of SURVEY.md."""
+    for n in (10, 20, 50, 60):
+        r = Regev.new_from_n(n)
+        assert is_prime(r.q) and -(-n ** 3 // 2) <= r.q <= n ** 3
+        assert r.m == (n + 1) * (r.q - 1).bit_length()
+        r.check_correctness(); r.check_security()
+    with pytest.raises(ValueError):
+        Regev.new_from_n(9)
+    d = Regev.default()
+    assert (d.n, d.m, d.q, float(d.alpha)) == (13, 154, 1427, 0.01)
+    d.check_correctness(); d.check_security()
+    s = Regev.secure128()
+    assert (s.n, s.m, s.q) == (230, 5313, 7764299)
+    with pytest.raises(MathError):
+        Regev(13, 50, 1427, 0.01).check_security()      # m <= (n+1) log q
+    with pytest.raises(MathError):
+        Regev(13, 154, 1427, 0.5).check_correctness()   # alpha too large
+    with pytest.raises(ValueError):
+        Regev(3, 16, 1, 2)                               # modulus <= 1
+    assert Regev.gen_new_public_parameters(3)[1] <= 3 ** 5
+
+
+def test_lpr_and_ring_lpr_parameter_rules():
+    for n in (10, 64, 200):
+        l = LPR.new_from_n(n)
+        assert is_prime(l.q) and -(-n ** 3 // 2) <= l.q <= n ** 3
+        l.check_correctness(); l.check_security()
+    assert (LPR.default().n, LPR.default().q) == (10, 983)
+    assert (LPR.secure128().n, LPR.secure128().q) == (500, 76859609)
+    r = RingLPR.new_from_n(64)
+    r.check_correctness(); r.check_security()
+    assert r.q.get_degree() == 64 and r.q.is_anticyclic()
+    with pytest.raises(MathError):
+        RingLPR(12, 2399, 0.0039).check_correctness()   # n not a power of two
+    assert (RingLPR.default().n, RingLPR.default().q_int) == (16, 2399)
+    assert (RingLPR.secure128().n, RingLPR.secure128().q_int) == (512, 92897729)
+    assert DualRegev.default().m == 154
+
+
+def test_ring_message_encoding():
+    r = RingLPR.default()
+    assert r.mu_bits(65536).tolist() == [0, 0]                       # ring_lpr.rs:655-667
+    assert r.mu_bits(-5).tolist() == [5, 0]                          # |message|
+    assert unpack_bits(r.mu_bits(212)[None], 16)[0].tolist() == [(212 >> i) & 1 for i in range(16)]
+
+
+def test_sis_checks_without_gpu():
+    key = MatZq(np.zeros((5, 18), np.uint32), 11)
+    SISHash(key).check_security()                                    # sis.rs doc example (5,18,11)
+    with pytest.raises(MathError):
+        SISHash(MatZq(np.zeros((5, 10), np.uint32), 11)).check_security()
+    with pytest.raises(MathError):
+        SISHash.gen(0, 3, 7)
+    with pytest.raises(ValueError):
+        SISHash(key).hash(MatZq(np.zeros((1, 18), np.uint32), 11))  # not a column vector (sis.rs:237-265)
+
+
+def test_text_formats():
+    m = MatZq.from_str("[[1, 2],[3, 12]] mod 7")
+    assert m.entries.tolist() == [[1, 2], [3, 5]] and repr(m) == "[[1, 2],[3, 5]] mod 7"
+    assert MatZq.from_str("[[1],[2],[3]] mod 7").is_column_vector()
+    assert MatZ.from_str("[[1],[5],[-1],[9]]").entries[:, 0].tolist() == [1, 5, -1, 9]
+    assert parse_poly("4  2 8 8 12") == [2, 8, 8, 12] and parse_poly("0") == []
+    assert format_poly([2, 8, 8, 12, 0]) == "4  2 8 8 12" and format_poly([0, 0]) == "0"
+    s = MatPolyOverZ.from_str("[[4  -1 7 6 -8, 3  0 -2 4, 4  0 3 -4 1, 4  6 4 -1 3]]", 4)
+    assert s.entries.tolist() == [[-1, 7, 6, -8], [0, -2, 4, 0], [0, 3, -4, 1], [6, 4, -1, 3]]
+
+
+def test_utils_match_reference_kats():
+    assert rot_minus([[1], [5], [-1], [9]]).tolist() == [[1, -9, 1, -5], [5, 1, -9, 1], [-1, 5, 1, -9], [9, -1, 5, 1]]
+    assert rot_minus([[1, 5, -1, 9]]).tolist() == rot_minus([1, 5, -1, 9]).tolist()
+    with pytest.raises(ValueError):
+        rot_minus([[1, 5, -1, 9], [1, 2, 3, 4]])
+    u = 2 ** 64 - 1
+    assert rot_minus_matrix([[1, 5, -1, 9], [u, 1, 2, 3]]).tolist() == [[1, -u, 5, -1, -1, -2, 9, -3], [u, 1, 1, 5, 2, -1, 3, 9]]
+    assert new_anticyclic(4, 17).coeffs.tolist() == [1, 0, 0, 0, 1]     # common_moduli.rs:99-111
+    assert new_cyclic(3, 7).coeffs.tolist() == [6, 0, 0, 1]
+    with pytest.raises(ValueError):
+        new_anticyclic(0, 7)
+
+
+def test_sha_hashes_host():
+    assert sha256("Hello World!") == "7f83b1657ff1fc53b92dc18148a1d65dfc2d4b1fa3d677284addd200126d9069"
+    assert hash_to_zq_sha256("Hello World!", 7) == 2 and hash_to_zq_sha256("qfall", 16) == 12
+    assert hash_to_mat_zq_sha256("Hello World!", 2, 2, 256) == MatZq.from_str("[[159, 26],[249, 141]] mod 256")
+    with pytest.raises(ValueError):
+        hash_to_mat_zq_sha256("x", 0, 2, 7)
+
+
+def test_gadget_parameters_and_norm_bound():
+    gp = GadgetParametersRing.init_default(8, 512)
+    assert gp.k == 9 and gp.modulus.get_degree() == 8
+    psf = PSFGPVRing(gp, 100)
+    assert psf.mbar == 11 and psf.norm_bound() == 100 * 100 * 8 * 11
+    assert GadgetParametersRing(1024, 1073479681).k == 30
+
+
+def test_bit_packing_helpers():
+    rng = np.random.default_rng(0)
+    b = rng.integers(0, 2, (5, 867)).astype(np.uint8)
+    p = pack_bits(b)
+    assert p.shape == (5, bit_stride(867)) and bit_stride(867) % 16 == 0
+    assert np.array_equal(unpack_bits(p, 867), b)
+    assert gaussian_width(0) == 0 and gaussian_width(6711) == 2319

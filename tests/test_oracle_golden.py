@@ -1,0 +1,173 @@
+"""CPU: pins the oracle (C restatement + exact Python) to the reference's own known-answer tests
+and to the committed seeded vectors (tests/golden/, see make_golden.py for provenance)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import coracle as co
+from oracle import pyoracle as po
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+KATS = json.load(open(os.path.join(G, "reference_kats.json")))
+VEC = json.load(open(os.path.join(G, "oracle_vectors.json")))
+SEED = 0x5146414C4C
+
+
+def test_rot_minus_kat():
+    """utils/rotation_matrix.rs:110-121."""
+    k = KATS["rot_minus"]
+    assert po.rot_minus(k["vec"]) == k["expected"]
+    assert co.rot_minus_i64(k["vec"]).tolist() == k["expected"]
+
+
+def test_rot_minus_matrix_kat():
+    """utils/rotation_matrix.rs:125-138 (entries up to u64::MAX: exact Python ints)."""
+    k = KATS["rot_minus_matrix"]
+    assert po.rot_minus_matrix(k["mat"]) == k["expected"]
+
+
+def test_negacyclic_product_equals_rot_minus_times_vector():
+    """Rot^-(a)*b == a*b mod (X^n+1): ties the product convention to the rot_minus KAT."""
+    rng = np.random.default_rng(1)
+    for n, q in [(4, 16), (8, 257), (16, 2399)]:
+        a = [int(v) for v in rng.integers(0, q, n)]
+        b = [int(v) for v in rng.integers(0, q, n)]
+        rot = po.rot_minus(a)
+        via_rot = [sum(rot[i][j] * b[j] for j in range(n)) % q for i in range(n)]
+        assert via_rot == po.polymul_negacyclic(a, b, q)
+        assert via_rot == co.polymul_batch(np.array([a]), np.array([b]), q)[0].tolist()
+        assert np.array_equal(co.rot_minus_modq(a, q), np.array(rot, dtype=object) % q)
+
+
+def test_fixed_ring_trapdoor_kat():
+    """short_basis_ring.rs:357-378 with gadget_ring.rs:71-77: a_{2+i} = 2^i - (a_bar*r_i + e_i)
+    in Z_16[X]/(X^4+1) -- a known answer for the negacyclic product from the reference's tests."""
+    k = KATS["ring_trapdoor_n4_q16"]
+    n, q = k["n"], k["q"]
+    pad = lambda p: list(p) + [0] * (n - len(p))
+    a = [pad(p) for p in k["a"]]
+    assert a[0] == [1, 0, 0, 0]
+    for i in range(4):
+        r = [c % q for c in pad(k["r"][i])]
+        e = pad(k["e"][i])
+        ar_py = po.polymul_negacyclic(a[1], r, q)
+        ar_c = co.polymul_batch(np.array([a[1]]), np.array([r]), q)[0].tolist()
+        assert ar_py == ar_c
+        g = [1 << i, 0, 0, 0]
+        assert [(g[j] - ar_py[j] - e[j]) % q for j in range(n)] == a[2 + i]
+    # and as an FDH-style f_a: a * [e ; r ; I] = g^t  (gadget_ring.rs:189-210 is_trapdoor)
+    for i in range(4):
+        col = [pad(k["e"][i]), pad(k["r"][i])] + [[1 if (j == i and t == 0) else 0 for t in range(n)] for j in range(4)]
+        t = po.fdh_ring_f_a(a, col, q)
+        assert t == [(1 << i) % q, 0, 0, 0]
+        tc, _ = co.fdh_ring_verify_batch(np.array(a), q, np.array([col], dtype=np.int32), np.zeros((1, n), np.uint32), 10 ** 6)
+        assert tc[0].tolist() == t
+
+
+def test_sha256_kats():
+    """construction/hash/sha256.rs:35,60,104,270-332."""
+    for s, h in KATS["sha256"].items():
+        assert po.sha256_hex(s) == h and co.sha256(s.encode()).hex() == h
+    for s, q, v in KATS["hash_to_zq"]:
+        assert po.hash_to_zq(s, q) == v and co.hash_to_zq(s, q) == v
+    for s, r, c, q, m in KATS["hash_to_mat_zq"]:
+        assert po.hash_to_mat_zq(s, r, c, q) == m and co.hash_to_mat_zq(s, r, c, q).tolist() == m
+
+
+def test_sha256_padding_lengths():
+    import hashlib
+    for ln in [0, 1, 55, 56, 63, 64, 65, 119, 120, 200]:
+        d = bytes((i * 7 + 3) & 255 for i in range(ln))
+        assert co.sha256(d) == hashlib.sha256(d).digest()
+
+
+def test_generator_c_vs_python():
+    q = 1073741789
+    assert co.sample_uniform(SEED, 1, 3, 50, q).tolist() == po.sample_uniform(SEED, 1, 3, 50, q)
+    assert co.sample_noise(SEED, 4, 9, 40, q, 300).tolist() == po.sample_noise(SEED, 4, 9, 40, q, 300)
+    bits = co.sample_bits(SEED, 3, 2, 3, 77, 16)
+    ref = po.sample_bits(SEED, 3, 2, 3, 77)
+    assert np.unpackbits(bits, axis=1, bitorder="little")[:, :77].tolist() == ref
+    assert not np.unpackbits(bits, axis=1, bitorder="little")[:, 77:].any()
+
+
+@pytest.mark.parametrize("case", VEC["regev"])
+def test_regev_vectors(case):
+    n, m, q, B = case["n"], case["m"], case["q"], case["B"]
+    pk = co.sample_uniform(SEED, 1, 0, (n + 1) * m, q).reshape(n + 1, m)
+    xb = co.sample_bits(SEED, 3, 0, B, m, ((m + 127) // 128) * 16)
+    msg = np.array(case["msg"], np.uint8)
+    c = co.matmul_batch(pk, q, xb, co.X_BITS, B, msg=msg)
+    assert c.tolist() == case["cipher"]
+    s = co.sample_uniform(SEED, 2, 0, n, q)
+    assert co.dot_decode_batch(s, q, c).tolist() == case["dec_with_stream2_secret"]
+
+
+@pytest.mark.parametrize("case", VEC["lpr"])
+def test_lpr_vectors(case):
+    n, q, W, B = case["n"], case["q"], case["W"], case["B"]
+    pk = co.sample_uniform(SEED, 1, 0, (n + 1) * n, q).reshape(n + 1, n)
+    r = co.sample_noise(SEED, 3, 0, B * n, q, W).reshape(B, n)
+    e = co.sample_noise(SEED, 4, 0, B * (n + 1), q, W).reshape(B, n + 1)
+    c = co.matmul_batch(pk, q, r, co.X_U32, B, addend=e, msg=np.array(case["msg"], np.uint8))
+    assert c.tolist() == case["cipher"]
+
+
+@pytest.mark.parametrize("case", VEC["ring_lpr"])
+def test_ring_lpr_vectors(case):
+    n, q, W, B = case["n"], case["q"], case["W"], case["B"]
+    a = co.sample_uniform(SEED, 1, 0, n, q)
+    s = co.sample_noise(SEED, 2, 0, n, q, W)
+    b = np.array(case["b"], np.uint32)
+    r = co.sample_noise(SEED, 3, 0, B * n, q, W).reshape(B, n)
+    e1 = co.sample_noise(SEED, 4, n, B * n, q, W).reshape(B, n)
+    e2 = co.sample_noise(SEED, 4, n + B * n, B * n, q, W).reshape(B, n)
+    mu = co.sample_bits(SEED, 5, 0, B, n, (n + 7) // 8)
+    u, v = co.ringlpr_enc_batch(a, b, q, r, e1, e2, mu)
+    assert u.tolist() == case["u"] and v.tolist() == case["v"]
+    dec = np.unpackbits(co.ringlpr_dec_batch(s, q, u, v), axis=1, bitorder="little")[:, :n]
+    assert dec.tolist() == case["dec"]
+
+
+@pytest.mark.parametrize("case", VEC["polymul"])
+def test_polymul_vectors(case):
+    n, q, B = case["n"], case["q"], case["B"]
+    a = co.sample_uniform(SEED, 6, 0, B * n, q).reshape(B, n)
+    b = co.sample_uniform(SEED, 6, B * n, B * n, q).reshape(B, n)
+    assert co.polymul_batch(a, b, q).tolist() == case["c"]
+    if co.find_psi(n, q):
+        assert co.polymul_batch(a, b, q, use_ntt=True).tolist() == case["c"]
+
+
+def test_cpu_ntt_equals_schoolbook():
+    n, q = 1024, 1073479681
+    a = co.sample_uniform(SEED, 6, 0, 2 * n, q).reshape(2, n)
+    b = co.sample_uniform(SEED, 6, 5000, 2 * n, q).reshape(2, n)
+    assert np.array_equal(co.polymul_batch(a, b, q, use_ntt=True), co.polymul_batch(a, b, q))
+    with pytest.raises(ValueError):
+        co.polymul_batch(a, b, 1073741789, use_ntt=True)
+
+
+def test_decision_rule_and_round_trip_semantics():
+    """regev.rs:445-451 ties -> 0; message mod 2 incl. negatives (regev.rs:598-612)."""
+    q = 1427
+    assert po.decide_bit(0, q) == 0 and po.decide_bit(q // 2, q) == 1
+    for r in range(q):
+        assert co.lib().qfo_decide_bit(r, q) == po.decide_bit(r, q)
+    assert po.decide_bit(4, 16) == 0  # equidistant from 0 and 8 -> 0
+    assert (-(2 ** 63)) % 2 == 0 and (2 ** 63 - 1) % 2 == 1
+    assert po.message_to_mu_bits(65536, 16) == [0] * 16  # ring_lpr.rs:655-667
+    assert co.regev_cycle(50, 867, 124991, 96, SEED, 1) == 1
+    assert co.regev_cycle(13, 154, 1427, 5, SEED, 0) == 0
+
+
+def test_multithreaded_variants_agree():
+    n, m, q, B = 20, 100, 7993, 37
+    pk = co.sample_uniform(SEED, 1, 0, (n + 1) * m, q).reshape(n + 1, m)
+    xb = co.sample_bits(SEED, 3, 0, B, m, 16)
+    c1 = co.matmul_batch(pk, q, xb, co.X_BITS, B)
+    assert np.array_equal(c1, co.matmul_batch(pk, q, xb, co.X_BITS, B, mt=True))
+    s = co.sample_uniform(SEED, 2, 0, n, q)
+    assert np.array_equal(co.dot_decode_batch(s, q, c1), co.dot_decode_batch(s, q, c1, mt=True))
