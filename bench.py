@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): batched Regev enc+dec, n=256, m=6168, q=16,777,213,
+65,536 one-bit messages per GPU, through the C ABI on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one pass of the hot path over one batch: encrypt B messages (kernel a, int8-MFMA mod-q
+GEMM) and decrypt them (batched dot-decode).  Inputs (public key, bit-packed randomness x,
+message bits) are generated on the device by the seeded generator and are resident in HBM when
+the timed region starts.  Multi-GPU: one process per GPU; rank 0 generates the key, the uint32
+key matrix is replicated with ONE RCCL broadcast, every rank recodes it locally and encrypts
+its own shard of B messages (weak scaling, no collective on the data path).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the GEMM): algorithmic
+int8 ops per launch / its mean launch duration measured with HIP events on the launch stream
+inside the timed region.  `cpu_baseline` is the C restatement of the reference (oracle/,
+one message per call) timed on the host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+SEED = 0x5146414C4C
+INT8_PEAK_TOPS = 5033.0   # 2048 int8 op/clk/SIMD x 1024 SIMDs x 2.4 GHz (MI355X_MICROARCH.md "Matrix cores": I8 = 2x BF16)
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=65536, help="messages per GPU per step")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-ring", action="store_true", help="skip the secondary ring-polymul measurement")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from crypto_amd.device import Context, X_BITS, bit_stride
+    ctx = Context(local)
+    dev = ctx.device
+
+    # ---- workload: BASELINE config 2 -------------------------------------------------------
+    n, m, q = 256, 6168, 16777213
+    B = args.batch
+    W = 4  # noise half-width of the Gaussian stand-in: |e| <= 16, far inside the q/4 decryption margin
+    la, lb = 3, 1
+    ops_per_enc = 2 * la * lb * (n + 1) * m            # algorithmic int8 ops (9,511,056)
+
+    # key generation on rank 0 (regev.rs:350-374), then ONE broadcast of the uint32 key
+    pk = ctx.empty_u32(n + 1, m)
+    s = ctx.empty_u32(n)
+    if rank == 0:
+        ctx.sample_uniform(SEED, 1, 0, n * m, q, out=pk[:n].view(-1))
+        ctx.sample_uniform(SEED, 2, 0, n, q, out=s)
+        e = ctx.sample_noise(SEED, 4, 0, m, q, W)
+        key_a = ctx.key_upload(pk[:n].contiguous(), q)
+        bvec = ctx.empty_u32(m)
+        assert ctx.lib.qf_vecmat_modq_dev(ctx.h, key_a.h, s.data_ptr(), bvec.data_ptr()) == 0
+        pk[n] = ((bvec.to(torch.int64) & 0xFFFFFFFF) + (e.to(torch.int64) & 0xFFFFFFFF)).remainder(q).to(torch.int32)
+        key_a.close()
+    t_bcast = 0.0
+    if world > 1:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dist.broadcast(pk, src=0)
+        dist.broadcast(s, src=0)
+        torch.cuda.synchronize()
+        t_bcast = time.perf_counter() - t0
+    key = ctx.key_upload(pk, q)
+    w = ((q - (s.to(torch.int64) & 0xFFFFFFFF)) % q).to(torch.int32)
+
+    # this rank's shard of the batch: rows [rank*B, (rank+1)*B) of the global generator streams
+    xbits = ctx.sample_bits(SEED, 3, rank * B, B, m)
+    msg = (ctx.sample_uniform(SEED, 5, rank * B, B, 2) & 1).to(torch.uint8)
+    cipher = ctx.empty_u32(B, n + 1)
+    bits = ctx.empty_u8(B)
+
+    def step():
+        ctx.matmul(key, xbits, X_BITS, B, msg=msg, out=cipher)
+        ctx.dot_decode(w, q, cipher, out=bits)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    assert torch.equal(bits, msg), "round trip failed: decrypted bits differ from the messages"
+
+    # ---- timed region ------------------------------------------------------------------------
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
+           torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        ctx.matmul(key, xbits, X_BITS, B, msg=msg, out=cipher)
+        ev[k][1].record()
+        ctx.dot_decode(w, q, cipher, out=bits)
+        ev[k][2].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.equal(bits, msg)
+
+    gemm_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in ev]))
+    dec_ms = float(np.mean([b.elapsed_time(c) for _, b, c in ev]))
+    value = world * B * args.steps / elapsed
+    achieved_tops = ops_per_enc * B / (gemm_ms * 1e-3) / 1e12
+
+    out = {
+        "metric": "encryptions/sec", "value": value, "unit": "encryptions/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int8 digits, i32/i64 accumulate (exact Z_q)",
+        "data": "synthetic (seeded SplitMix64 on device)",
+        "config": {"workload": "Regev enc+dec round trip (BASELINE config 2)", "n": n, "m": m, "q": q,
+                   "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"batch-shard x{world}",
+                   "key_broadcast_ms": t_bcast * 1e3},
+        "roofline": {"kernel": "qf_gemm_kernel<3,1,3,bits>", "bound": "mfma", "achieved": achieved_tops,
+                     "peak": INT8_PEAK_TOPS, "unit": "TFLOP/s", "frac": achieved_tops / INT8_PEAK_TOPS,
+                     "traffic": None, "launch_ms": gemm_ms,
+                     "note": "int8 multiply-accumulates counted as 2 ops; algorithmic ops = 2*La*Lb*(n+1)*m per encryption"},
+        "decode": {"kernel": "qf_dot_decode_kernel", "bound": "hbm", "launch_ms": dec_ms,
+                   "achieved": B * (n + 1) * 4 / (dec_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": B * (n + 1) * 4 / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+    }
+
+    # ---- secondary headline: ring products n=1024 (BASELINE config 5 (i)) --------------------
+    if not args.no_ring:
+        nr, qr, Br = 1024, 1073479681, 1 << 16
+        ring = ctx.ring(nr, qr)
+        a = ctx.sample_uniform(SEED, 6, rank * 2 * Br * nr, Br * nr, qr).view(Br, nr)
+        b = ctx.sample_uniform(SEED, 6, (rank * 2 + 1) * Br * nr, Br * nr, qr).view(Br, nr)
+        c = torch.empty_like(a)
+        for _ in range(2):
+            ring.polymul(a, b, out=c)
+        torch.cuda.synchronize()
+        rs = max(3, args.steps // 2)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if world > 1:
+            dist.barrier()
+        e0.record()
+        for _ in range(rs):
+            ring.polymul(a, b, out=c)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / rs
+        rate = Br / (ms * 1e-3)
+        if world > 1:
+            tt = torch.tensor([rate], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+            rate = float(tt.item())
+        gbs = Br * 3 * 4 * nr / (ms * 1e-3) / 1e9
+        out["ring_polymul"] = {"metric": "ring-polymuls/sec (n=1024, q=2^30-2^18+1)", "value": rate, "unit": "polymuls/s",
+                               "batch_per_gpu": Br, "launch_ms": ms,
+                               "roofline": {"kernel": "qf_ring_ntt_kernel<polymul>", "bound": "hbm", "achieved": gbs,
+                                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                            "traffic": None, "note": "algorithmic bytes = 12,288 per product (2 in, 1 out)"}}
+
+    # ---- CPU baseline (rank 0, single-GPU run only) -----------------------------------------
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle import coracle as co
+        pk_h = ctx.to_host_u32(pk)
+        s_h = ctx.to_host_u32(s)
+        threads = co.num_threads()
+        probe = 64
+        xb_h = ctx.to_host_u8(xbits[:probe])
+        t1 = time.perf_counter()
+        co.matmul_batch(pk_h, q, xb_h, co.X_BITS, probe)
+        per_msg_1t = (time.perf_counter() - t1) / probe
+        sample = int(min(B, max(threads * 16, args.cpu_seconds / per_msg_1t * threads * 0.5)))
+        xb_h = ctx.to_host_u8(xbits[:sample])
+        msg_h = ctx.to_host_u8(msg[:sample])
+        t1 = time.perf_counter()
+        c_h = co.matmul_batch(pk_h, q, xb_h, co.X_BITS, sample, msg=msg_h, mt=True)
+        b_h = co.dot_decode_batch(s_h, q, c_h, mt=True)
+        cpu_t = time.perf_counter() - t1
+        assert np.array_equal(b_h, msg_h)
+        assert np.array_equal(c_h, ctx.to_host_u32(cipher[:sample])), "GPU ciphertexts differ from the CPU oracle"
+        out["cpu_baseline"] = {"value": sample / cpu_t, "unit": "encryptions/s", "cores": threads, "kind": "port",
+                               "sample": f"{sample} of the same {B} messages (enc+dec, one message per call as the reference does, "
+                                         f"OpenMP over messages); single-thread rate {1.0 / per_msg_1t:.1f}/s on a {probe}-message probe; "
+                                         "GPU ciphertexts of the sample verified bit-identical"}
+    elif rank == 0:
+        out["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

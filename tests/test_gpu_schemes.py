@@ -131,7 +131,10 @@ def test_ring_lpr_message_wraps_mod_2n(ctx):
 
 def test_ring_lpr_n1024_ntt_friendly(ctx):
     """BASELINE config 5: n=1024, q = 2^30 - 2^18 + 1."""
-    s = RingLPR(1024, 1073479681, 1 / (5 * 32 * 1000), ctx=ctx)
+    # alpha is taken 64x below new_from_n(1024)'s value: at n=1024 the reference's own alpha
+    # (ring_lpr.rs:183-191, "found out by experience" for small n) gives decryption noise of
+    # about q/3 and does not round-trip; the arithmetic parity below does not depend on alpha.
+    s = RingLPR(1024, 1073479681, 1 / (5 * 32 * 1000 * 64), ctx=ctx)
     assert s.ring.uses_ntt
     pk, sk = s.gen()
     msgs = [0, 1, 2 ** 1024 - 1, 3 ** 600, 2 ** 1023 + 12345]
