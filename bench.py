@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-ring", action="store_true", help="skip the secondary ring-polymul measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--workload", default="regev", choices=["regev", "sis", "lpr", "ringlpr", "fdh", "matvec"],
+                    help="regev = the headline (BASELINE config 2); the others are the remaining configs, "
+                         "each printing its own JSON line")
     return ap.parse_args()
 
 
@@ -216,5 +219,164 @@ def main():
         dist.destroy_process_group()
 
 
+def _time_loop(fn, steps, warmup, dist, world):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    return el, float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+
+def other_workloads(args):
+    """Configs 3-5 of BASELINE.json (not the headline line): same conventions, one JSON line."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from crypto_amd.device import Context, X_BITS, X_U32
+    from crypto_amd import sharding
+    ctx = Context(local)
+    wl = args.workload
+    out = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+           "vs_baseline": None, "data": "synthetic (seeded SplitMix64 on device)"}
+    if wl == "sis":
+        n, q = 512, 8380417
+        m = n * 23
+        Btot = 1 << 20
+        lo, hi = sharding.shard_range(Btot, rank, world)
+        B = hi - lo
+        A = ctx.sample_uniform(SEED, 1, 0, n * m, q).view(n, m)   # same seeded key on every rank == a broadcast key
+        key = ctx.key_upload(A, q)
+        xb = ctx.sample_bits(SEED, 3, lo, B, m)
+        dig = ctx.empty_u32(B, n)
+        el, ms = _time_loop(lambda: ctx.matmul(key, xb, X_BITS, B, out=dig), args.steps, args.warmup, dist, world)
+        ops = 2 * 3 * n * m
+        tops = ops * B / (ms * 1e-3) / 1e12
+        out.update({"metric": "SIS hashes/sec", "value": Btot * args.steps / el, "unit": "hashes/s", "scaling": "strong",
+                    "ms_per_step": el / args.steps * 1e3, "dtype": "int8 digits (exact Z_q)",
+                    "config": {"workload": "SIS hash, binary inputs (BASELINE config 3)", "n": n, "m": m, "q": q, "global_batch": Btot},
+                    "roofline": {"kernel": "qf_gemm_kernel<3,1,*,bits>", "bound": "mfma", "achieved": tops, "peak": INT8_PEAK_TOPS,
+                                 "unit": "TFLOP/s", "frac": tops / INT8_PEAK_TOPS, "traffic": None, "launch_ms": ms}})
+        # linearity property at full size: H(x) + H(y) == H(x xor y) + 2*H(x and y)  (mod q)
+        if rank == 0:
+            k = min(B, 4096)
+            x, y = xb[:k], ctx.sample_bits(SEED, 7, 0, k, m)
+            hx = ctx.matmul(key, x, X_BITS, k).to(torch.int64)
+            hy = ctx.matmul(key, y, X_BITS, k).to(torch.int64)
+            hxor = ctx.matmul(key, x ^ y, X_BITS, k).to(torch.int64)
+            hand = ctx.matmul(key, x & y, X_BITS, k).to(torch.int64)
+            assert torch.equal((hx + hy) % q, (hxor + 2 * hand) % q), "SIS linearity violated"
+    elif wl == "lpr":
+        n, q, W = 1024, 1073741789, 2319
+        Btot = 1 << 18
+        lo, hi = sharding.shard_range(Btot, rank, world)
+        B = hi - lo
+        pk = ctx.sample_uniform(SEED, 1, 0, (n + 1) * n, q).view(n + 1, n)
+        key = ctx.key_upload(pk, q)
+        r = ctx.sample_noise(SEED, 3, lo * n, B * n, q, W).view(B, n)
+        e = ctx.sample_noise(SEED, 4, lo * (n + 1), B * (n + 1), q, W).view(B, n + 1)
+        msg = (ctx.sample_uniform(SEED, 5, lo, B, 2) & 1).to(torch.uint8)
+        c = ctx.empty_u32(B, n + 1)
+        ctx.set_timing(False)
+        el, ms = _time_loop(lambda: ctx.matmul(key, r, X_U32, B, addend=e, msg=msg, x_digits=2, out=c), args.steps, args.warmup, dist, world)
+        ctx.set_timing(True)
+        ctx.matmul(key, r, X_U32, B, addend=e, msg=msg, x_digits=2, out=c)
+        gemm_ms = ctx.last_kernel_ms("gemm")
+        ctx.set_timing(False)
+        ops = 2 * 4 * 2 * (n + 1) * n
+        tops = ops * B / (gemm_ms * 1e-3) / 1e12
+        gbs = B * (4 * n + 8 * (n + 1)) / (ms * 1e-3) / 1e9
+        out.update({"metric": "LPR encryptions/sec", "value": Btot * args.steps / el, "unit": "encryptions/s", "scaling": "strong",
+                    "ms_per_step": el / args.steps * 1e3, "dtype": "int8 digits (exact Z_q)",
+                    "config": {"workload": "LPR enc (BASELINE config 4), r recoded to 2 signed digits (verified on device)",
+                               "n": n, "q": q, "global_batch": Btot},
+                    "roofline": {"kernel": "qf_gemm_kernel<4,2,*,planes>", "bound": "mfma", "achieved": tops, "peak": INT8_PEAK_TOPS,
+                                 "unit": "TFLOP/s", "frac": tops / INT8_PEAK_TOPS, "traffic": None, "launch_ms": gemm_ms,
+                                 "whole_call_ms": ms, "hbm_frac_whole_call": gbs / HBM_PEAK_GBS}})
+    elif wl in ("ringlpr", "fdh"):
+        n, q, W = 1024, 1073479681, 36
+        ring = ctx.ring(n, q)
+        if wl == "ringlpr":
+            Btot = 1 << 18
+            lo, hi = sharding.shard_range(Btot, rank, world)
+            B = hi - lo
+            keys = ctx.sample_uniform(SEED, 1, 0, 2 * n, q).view(2, n)
+            pk = ring.key(keys)
+            r = ctx.sample_noise(SEED, 3, lo * n, B * n, q, W).view(B, n)
+            e1 = ctx.sample_noise(SEED, 4, lo * n, B * n, q, W).view(B, n)
+            e2 = ctx.sample_noise(SEED, 8, lo * n, B * n, q, W).view(B, n)
+            mu = ctx.sample_bits(SEED, 5, lo, B, n, n // 8)
+            u, v = torch.empty_like(r), torch.empty_like(r)
+            el, ms = _time_loop(lambda: ring.ringlpr_enc(pk, r, e1, e2, mu, u=u, v=v), args.steps, args.warmup, dist, world)
+            bytes_per = 5 * 4 * n + n // 8
+            out.update({"metric": "RingLPR encryptions/sec (= 2 ring products each)", "value": Btot * args.steps / el, "unit": "encryptions/s"})
+        else:
+            mbar = 32
+            Btot = 1 << 15
+            lo, hi = sharding.shard_range(Btot, rank, world)
+            B = hi - lo
+            a = ring.key(ctx.sample_uniform(SEED, 1, 0, mbar * n, q).view(mbar, n))
+            sig = (ctx.sample_uniform(SEED, 7, lo * mbar * n, B * mbar * n, 201) - 100).view(B, mbar, n)
+            uu = ctx.sample_uniform(SEED, 6, lo * n, B * n, q).view(B, n)
+            el, ms = _time_loop(lambda: ring.fdh_verify(a, sig, uu, 10 ** 12), args.steps, args.warmup, dist, world)
+            bytes_per = (mbar + 1) * 4 * n
+            out.update({"metric": "GPV-ring FDH verifications/sec (k+2 = 32 ring products each)", "value": Btot * args.steps / el, "unit": "verifications/s"})
+        gbs = B * bytes_per / (ms * 1e-3) / 1e9
+        out.update({"scaling": "strong", "ms_per_step": el / args.steps * 1e3, "dtype": "u32 (exact Z_q, Shoup NTT)",
+                    "config": {"workload": f"{wl} n=1024 (BASELINE config 5)", "n": n, "q": q, "global_batch": Btot},
+                    "roofline": {"kernel": "qf_ring_ntt_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "launch_ms": ms}})
+    elif wl == "matvec":
+        # single-message SIS hash, matrix cache-cold: rotate over > 256 MiB of distinct keys
+        n, q = 512, 8380417
+        m = n * 23
+        nkeys = 14
+        keys = [ctx.key_upload(ctx.sample_uniform(SEED, 1, i * n * m, n * m, q).view(n, m), q) for i in range(nkeys)]
+        x = ctx.sample_uniform(SEED, 6, 0, m, 2)
+        y = ctx.empty_u32(n)
+        state = {"i": 0}
+
+        def one():
+            k = keys[state["i"] % nkeys]
+            state["i"] += 1
+            assert ctx.lib.qf_matvec_modq_dev(ctx.h, k.h, x.data_ptr(), y.data_ptr()) == 0
+        el, ms = _time_loop(one, max(args.steps, nkeys * 2), nkeys, dist, world)
+        gbs = 4 * n * m / (ms * 1e-3) / 1e9
+        out.update({"metric": "single-message SIS hashes/sec (HBM-streaming mat-vec, cache-cold keys)",
+                    "value": world * max(args.steps, nkeys * 2) / el, "unit": "hashes/s", "scaling": "weak",
+                    "ms_per_step": ms, "dtype": "u32 (exact Z_q)",
+                    "config": {"workload": "SIS mat-vec n=512 m=11776, 14 keys = 338 MB rotated", "n": n, "m": m, "q": q},
+                    "roofline": {"kernel": "qf_matvec_partial+finish", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "launch_ms": ms}})
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 if __name__ == "__main__":
-    main()
+    _a = parse()
+    if _a.workload == "regev":
+        main()
+    else:
+        other_workloads(_a)

@@ -20,6 +20,7 @@
 //   PLANES : pre-recoded digit fragments are loaded with one coalesced 16-byte load per lane.
 // MFMA roles: A (rows of D) = messages, B (columns of D) = key rows, so a lane ends up owning
 // one key row and 16 messages, and every store instruction writes two 128-byte runs.
+#include <cstdlib>
 #include "qf_internal.h"
 
 #define QF_NW 8          // waves per workgroup
@@ -169,6 +170,9 @@ __device__ __forceinline__ v4i qf_expand16(uint32_t w16) {
 template <int LA, int LB, int WN, bool BITS>
 __global__ __launch_bounds__(QF_NW * 64, 2) void qf_gemm_kernel(QfGemmArgs a) {
     constexpr int S = LA + LB - 1;
+    // prefetch operand fragments one k-step ahead when both register sets fit next to the
+    // accumulators (2 waves/SIMD => 256 VGPRs per lane)
+    constexpr bool PF = WN * S * 16 + 8 * (WN * LA + LB) <= 224;
     constexpr int FRAGS = WN * QF_KS * LA;           // key fragments (1 KiB each) per k-tile
     constexpr int TILE_BYTES = FRAGS * 1024;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 2 * TILE_BYTES
@@ -234,26 +238,68 @@ __global__ __launch_bounds__(QF_NW * 64, 2) void qf_gemm_kernel(QfGemmArgs a) {
             if (off + 16 <= a.xstride) xb_next = *(const uint4 *)(xrow + off);
         }
         const uint8_t *tile = smem + buf * TILE_BYTES + lane * 16;
+        // Operand fragments are read one k-step ahead into a second register set so that the
+        // LDS (and, for PLANES, global) latency hides behind the previous k-step's MFMAs.
+        v4i bf[PF ? 2 : 1][WN * LA];
+        v4i af[PF ? 2 : 1][LB];
+#define QF_LOAD_B(set_, ks_)                                                                      \
+    _Pragma("unroll") for (int j_ = 0; j_ < WN; j_++)                                             \
+        _Pragma("unroll") for (int l_ = 0; l_ < LA; l_++)                                         \
+            bf[set_][j_ * LA + l_] = *(const v4i *)(tile + ((j_ * QF_KS + (ks_)) * LA + l_) * 1024);
+#define QF_LOAD_A(set_, ks_)                                                                      \
+    if (BITS) {                                                                                   \
+        const uint32_t w_ = (ks_) == 0 ? xb.x : (ks_) == 1 ? xb.y : (ks_) == 2 ? xb.z : xb.w;     \
+        af[set_][0] = qf_expand16(h ? (w_ >> 16) : (w_ & 0xFFFFu));                               \
+    } else {                                                                                      \
+        _Pragma("unroll") for (int b_ = 0; b_ < LB; b_++)                                         \
+            af[set_][b_] = *(const v4i *)(xfrag + (((size_t)kt * QF_KS + (ks_)) * LB + b_) * 1024); \
+    }
+        if constexpr (PF) {
+            QF_LOAD_B(0, 0)
+            QF_LOAD_A(0, 0)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < QF_KS; ks++) {
-            v4i af[LB];
-            if (BITS) {
-                uint32_t w = ks == 0 ? xb.x : ks == 1 ? xb.y : ks == 2 ? xb.z : xb.w;
-                af[0] = qf_expand16(h ? (w >> 16) : (w & 0xFFFFu));
-            } else {
-#pragma unroll
-                for (int b = 0; b < LB; b++)
-                    af[b] = *(const v4i *)(xfrag + (((size_t)kt * QF_KS + ks) * LB + b) * 1024);
-            }
-#pragma unroll
-            for (int j = 0; j < WN; j++) {
-#pragma unroll
-                for (int la = 0; la < LA; la++) {
-                    v4i bf = *(const v4i *)(tile + ((j * QF_KS + ks) * LA + la) * 1024);
-#pragma unroll
-                    for (int b = 0; b < LB; b++)
-                        acc[j][la + b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[b], bf, acc[j][la + b], 0, 0, 0);
+            for (int ks = 0; ks < QF_KS; ks++) {
+                const int cur = ks & 1, nxt = cur ^ 1;
+                if (ks + 1 < QF_KS) {
+                    QF_LOAD_B(nxt, ks + 1)
+                    QF_LOAD_A(nxt, ks + 1)
                 }
+#pragma unroll
+                for (int j = 0; j < WN; j++)
+#pragma unroll
+                    for (int la = 0; la < LA; la++)
+#pragma unroll
+                        for (int b = 0; b < LB; b++)
+                            acc[j][la + b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[cur][b], bf[cur][j * LA + la],
+                                                                                    acc[j][la + b], 0, 0, 0);
+                // pin the interleave: one next-k-step LDS read issued between consecutive MFMAs of
+                // this k-step (hipcc otherwise sinks every read to just before its use and waits
+                // lgkmcnt(0) in front of every MFMA)
+                if (ks + 1 < QF_KS) {
+#pragma unroll
+                    for (int i = 0; i < WN * LA; i++) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read (next k-step)
+                        __builtin_amdgcn_sched_group_barrier(0x008, LB, 0);  // LB MFMAs (this k-step)
+                    }
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, WN * LA * LB, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // k-steps are separate scheduling regions
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < QF_KS; ks++) {
+                QF_LOAD_A(0, ks)
+#pragma unroll
+                for (int j = 0; j < WN; j++)
+#pragma unroll
+                    for (int la = 0; la < LA; la++) {
+                        const v4i bfr = *(const v4i *)(tile + ((j * QF_KS + ks) * LA + la) * 1024);
+#pragma unroll
+                        for (int b = 0; b < LB; b++)
+                            acc[j][la + b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0][b], bfr, acc[j][la + b], 0, 0, 0);
+                    }
             }
         }
         xb = xb_next;
@@ -314,6 +360,10 @@ static int qf_gemm_dispatch(qf_ctx *ctx, const QfGemmArgs &args) {
     for (int w = WMAX; w >= 1; w--) {
         uint32_t tiles = (args.rb + w - 1) / w, waste = tiles * w - args.rb;
         if (waste < best_waste) { best_waste = waste; best = w; }
+    }
+    if (const char *e = getenv("QF_GEMM_WN")) {  // experiments only
+        int w = atoi(e);
+        if (w >= 1 && w <= WMAX) best = w;
     }
     switch (best) {
         case 1: return qf_gemm_dispatch_wn<LA, LB, 1, BITS>(ctx, args);
