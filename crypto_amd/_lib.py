@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libqfgpu.so")
+LIB_PATH = os.environ.get("QF_LIB_PATH") or os.path.join(_HERE, "lib", "libqfgpu.so")  # override: diagnostic builds only
 
 QF_OK, QF_ERR_ARG, QF_ERR_DIM, QF_ERR_MODULUS, QF_ERR_DEVICE, QF_ERR_RANGE, QF_ERR_NOTSUP = range(7)
 X_BITS, X_U32, X_I32 = 0, 1, 2

@@ -155,7 +155,19 @@ struct QfGemmArgs {
     uint32_t *out;           // B x rows
     QfMod mod;
     int32_t cs[8];           // centred 2^(8s) mod q
+    unsigned long long *dbg; // diagnostic build only (QF_STAMP): per-wave cycle sums
 };
+
+#ifdef QF_STAMP
+#define QF_T(var_) unsigned long long var_; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var_) :: "memory"); __builtin_amdgcn_sched_barrier(0);
+#define QF_ACC(sum_, a_, b_) sum_ += (b_) - (a_);
+#else
+#define QF_T(var_)
+#define QF_ACC(sum_, a_, b_)
+#endif
+static unsigned long long *g_qf_dbg = nullptr;
+extern "C" void qf_debug_set_buffer(void *p) { g_qf_dbg = (unsigned long long *)p; }
 
 // 16 bits -> 16 bytes of {0,1}: each nibble is spread over one dword (bit t -> byte t)
 __device__ __forceinline__ v4i qf_expand16(uint32_t w16) {
@@ -168,14 +180,14 @@ __device__ __forceinline__ v4i qf_expand16(uint32_t w16) {
 }
 
 template <int LA, int LB, int WN, bool BITS>
-__global__ __launch_bounds__(QF_NW * 64, 2) void qf_gemm_kernel(QfGemmArgs a) {
+__global__ __launch_bounds__(QF_NW * 64, (WN * (LA + LB - 1) * 16 <= 48 ? 4 : 2)) void qf_gemm_kernel(QfGemmArgs a) {
     constexpr int S = LA + LB - 1;
     // prefetch operand fragments one k-step ahead when both register sets fit next to the
     // accumulators (2 waves/SIMD => 256 VGPRs per lane)
     constexpr bool PF = WN * S * 16 + 8 * (WN * LA + LB) <= 224;
     constexpr int FRAGS = WN * QF_KS * LA;           // key fragments (1 KiB each) per k-tile
     constexpr int TILE_BYTES = FRAGS * 1024;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 2 * TILE_BYTES
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 3 * TILE_BYTES
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -198,19 +210,21 @@ __global__ __launch_bounds__(QF_NW * 64, 2) void qf_gemm_kernel(QfGemmArgs a) {
     // the destination of one wave-instruction is fragment base + lane*16, which is exactly the
     // linear fragment image the MFMA operand reads expect.
     constexpr int NSR = (FRAGS + QF_NW - 1) / QF_NW;
+    // Every wave issues exactly NSR DMA instructions per tile (a wave whose share runs past the
+    // tile re-copies the last fragment: same bytes to the same place), so the stream has no
+    // branches and hipcc can count vmcnt exactly around it.
 #define QF_STAGE(kt_, buf_)                                                                          \
     _Pragma("unroll") for (int i_ = 0; i_ < NSR; i_++) {                                             \
-        const int f_ = wave + i_ * QF_NW;                                                            \
-        if (f_ < FRAGS) {                                                                            \
-            const int j_ = f_ / (QF_KS * LA), rem_ = f_ % (QF_KS * LA);                              \
-            uint32_t rbi_ = rb0 + j_;                                                                \
-            if (rbi_ >= a.rb) rbi_ = a.rb - 1; /* padded column tile: harmless duplicate */          \
-            const int8_t *g_ = a.kplanes +                                                           \
-                ((((size_t)rbi_ * a.ks + (size_t)(kt_)*QF_KS) * LA + rem_) * 64 + lane) * 16;        \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g_,     \
-                (__attribute__((address_space(3))) void *)(smem + (buf_)*TILE_BYTES + f_ * 1024),    \
-                16, 0, 0);                                                                           \
-        }                                                                                            \
+        int f_ = wave + i_ * QF_NW;                                                                  \
+        f_ = f_ < FRAGS ? f_ : FRAGS - 1;                                                            \
+        const int j_ = f_ / (QF_KS * LA), rem_ = f_ % (QF_KS * LA);                                  \
+        uint32_t rbi_ = rb0 + j_;                                                                    \
+        rbi_ = rbi_ < a.rb ? rbi_ : a.rb - 1; /* padded column tile: harmless duplicate */           \
+        const int8_t *g_ = a.kplanes +                                                               \
+            ((((size_t)rbi_ * a.ks + (size_t)(kt_)*QF_KS) * LA + rem_) * 64 + lane) * 16;            \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g_,         \
+            (__attribute__((address_space(3))) void *)(smem + (buf_)*TILE_BYTES + f_ * 1024),        \
+            16, 0, 0);                                                                               \
     }
 
     // ---- batch operand addressing
@@ -221,90 +235,142 @@ __global__ __launch_bounds__(QF_NW * 64, 2) void qf_gemm_kernel(QfGemmArgs a) {
     const uint64_t mb_c = mb < nmb ? mb : nmb - 1;
     const int8_t *xfrag = BITS ? nullptr : a.xplanes + (mb_c * a.ks * LB) * 1024 + (size_t)lane * 16;
 
-    QF_STAGE(0, 0)
-    uint4 xb = make_uint4(0, 0, 0, 0);
-    if (BITS) {
-        if ((size_t)16 <= a.xstride) xb = *(const uint4 *)(xrow);
+    // ---- main loop.  Three LDS buffers: the DMA of k-tile t+2 is issued in the middle of tile t
+    // (about 1.5 tiles before its first use), so its ~1 us issue-to-landed latency never shows.
+    // One barrier per tile, placed mid-tile: every wave that passes it has (a) finished reading
+    // tile t-1's buffer, which the new DMA overwrites, and (b) seen its own DMA of tile t+1 land
+    // (vmcnt(0) in front of the barrier), so the last k-step of tile t can already prefetch the
+    // first fragments of tile t+1 and the MFMA stream runs across tile boundaries without a bubble.
+    // The batch operand of tile t+1 (16 bytes of bits, or KS*LB fragments) is loaded to registers
+    // at the same point but BEFORE the DMA is issued: vmcnt retires in order, so a load issued
+    // after the DMA could not be consumed until the DMA had landed.
+    constexpr int NAT = BITS ? 1 : QF_KS * LB;   // registers sets (16 B) of one tile's batch operand
+    constexpr bool ATILE = BITS || NAT <= 8;     // whole-tile register prefetch affordable
+    v4i at[2][ATILE ? NAT : 1];
+    v4i bf[PF ? 2 : 1][WN * LA];
+    v4i af[PF ? 2 : 1][LB];
+    // The tile's batch-operand loads are inline asm: hipcc waits vmcnt(0) for any compiler-visible
+    // load while an LDS-DMA is in flight, which would stall on the DMA issued right behind them.
+    // QF_WAIT_AT is the matching counted wait (all but the NSR younger DMA instructions retired).
+#define QF_LOAD_AT(set_, kt_)                                                                     \
+    if (BITS) {                                                                                   \
+        /* bits past the row's stride only ever meet zero-padded key columns: clamp, no branch */ \
+        size_t off_ = (size_t)(kt_)*16;                                                           \
+        off_ = off_ + 16 <= a.xstride ? off_ : a.xstride - 16;                                    \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(at[set_][0]) : "v"(xrow + off_) : "memory"); \
+    } else if (ATILE) {                                                                           \
+        _Pragma("unroll") for (int i_ = 0; i_ < NAT; i_++)                                        \
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(at[set_][i_])                   \
+                         : "v"(xfrag + ((size_t)(kt_)*QF_KS * LB + i_) * 1024) : "memory");       \
     }
-    __syncthreads();
-
-    for (uint32_t kt = 0; kt < ntiles; kt++) {
-        const int buf = kt & 1;
-        const bool more = kt + 1 < ntiles;
-        if (more) { QF_STAGE(kt + 1, buf ^ 1) }
-        uint4 xb_next = make_uint4(0, 0, 0, 0);
-        if (BITS && more) {
-            size_t off = (size_t)(kt + 1) * 16;
-            if (off + 16 <= a.xstride) xb_next = *(const uint4 *)(xrow + off);
-        }
-        const uint8_t *tile = smem + buf * TILE_BYTES + lane * 16;
-        // Operand fragments are read one k-step ahead into a second register set so that the
-        // LDS (and, for PLANES, global) latency hides behind the previous k-step's MFMAs.
-        v4i bf[PF ? 2 : 1][WN * LA];
-        v4i af[PF ? 2 : 1][LB];
-#define QF_LOAD_B(set_, ks_)                                                                      \
+#define QF_WAIT_AT(set_, n_)                                                                      \
+    if (BITS || ATILE) {                                                                          \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory");                                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < NAT; i_++) asm volatile("" : "+v"(at[set_][i_])); \
+    }
+#ifdef QF_ABL_NOLDS
+#define QF_LOAD_B(set_, tile_, ks_)                                                               \
     _Pragma("unroll") for (int j_ = 0; j_ < WN; j_++)                                             \
         _Pragma("unroll") for (int l_ = 0; l_ < LA; l_++)                                         \
-            bf[set_][j_ * LA + l_] = *(const v4i *)(tile + ((j_ * QF_KS + (ks_)) * LA + l_) * 1024);
-#define QF_LOAD_A(set_, ks_)                                                                      \
+            asm volatile("" : "+v"(bf[set_][j_ * LA + l_]));
+#else
+#define QF_LOAD_B(set_, tile_, ks_)                                                               \
+    _Pragma("unroll") for (int j_ = 0; j_ < WN; j_++)                                             \
+        _Pragma("unroll") for (int l_ = 0; l_ < LA; l_++)                                         \
+            bf[set_][j_ * LA + l_] = *(const v4i *)((tile_) + ((j_ * QF_KS + (ks_)) * LA + l_) * 1024);
+#endif
+#define QF_LOAD_A(set_, atset_, kt_, ks_)                                                         \
     if (BITS) {                                                                                   \
-        const uint32_t w_ = (ks_) == 0 ? xb.x : (ks_) == 1 ? xb.y : (ks_) == 2 ? xb.z : xb.w;     \
+        const uint32_t w_ = (uint32_t)at[atset_][0][ks_];                                         \
         af[set_][0] = qf_expand16(h ? (w_ >> 16) : (w_ & 0xFFFFu));                               \
+    } else if (ATILE) {                                                                           \
+        _Pragma("unroll") for (int b_ = 0; b_ < LB; b_++) af[set_][b_] = at[atset_][(ks_)*LB + b_]; \
     } else {                                                                                      \
         _Pragma("unroll") for (int b_ = 0; b_ < LB; b_++)                                         \
-            af[set_][b_] = *(const v4i *)(xfrag + (((size_t)kt * QF_KS + (ks_)) * LB + b_) * 1024); \
+            af[set_][b_] = *(const v4i *)(xfrag + (((size_t)(kt_)*QF_KS + (ks_)) * LB + b_) * 1024); \
     }
+#define QF_MFMAS(set_)                                                                            \
+    _Pragma("unroll") for (int j_ = 0; j_ < WN; j_++)                                             \
+        _Pragma("unroll") for (int l_ = 0; l_ < LA; l_++)                                         \
+            _Pragma("unroll") for (int b_ = 0; b_ < LB; b_++)                                     \
+                acc[j_][l_ + b_] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[set_][b_], bf[set_][j_ * LA + l_], \
+                                                                         acc[j_][l_ + b_], 0, 0, 0);
+    // pin the interleave: one prefetch LDS read between consecutive MFMA groups (hipcc otherwise
+    // sinks every read to just before its use and waits lgkmcnt(0) in front of every MFMA)
+#define QF_INTERLEAVE()                                                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < WN * LA; i_++) {                                      \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                        \
+        __builtin_amdgcn_sched_group_barrier(0x008, LB, 0);                                       \
+    }                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);
+
+    QF_LOAD_AT(0, 0)
+    QF_STAGE(0, 0)
+    QF_STAGE(ntiles > 1 ? 1 : 0, 1)
+    QF_WAIT_AT(0, 0)
+    __syncthreads();  // drains the DMA (vmcnt(0)) and synchronises the workgroup
+    if constexpr (PF) {
+        QF_LOAD_B(0, smem + lane * 16, 0)
+        QF_LOAD_A(0, 0, 0, 0)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+#ifdef QF_STAMP
+    unsigned long long s_vm = 0, s_bar = 0, s_at = 0, s_loop = 0, s_epi = 0;
+#endif
+    QF_T(tl0)
+    uint32_t buf = 0;
+    for (uint32_t kt = 0; kt < ntiles; kt++) {
+        const uint32_t buf1 = buf == 2 ? 0 : buf + 1, buf2 = buf1 == 2 ? 0 : buf1 + 1;
+        const uint8_t *tile = smem + buf * TILE_BYTES + lane * 16;
+        const uint8_t *tile1 = smem + buf1 * TILE_BYTES + lane * 16;
+        const uint32_t kt1 = kt + 1 < ntiles ? kt + 1 : kt;  // clamped: the tail prefetches are discarded
+        const uint32_t kt2 = kt + 2 < ntiles ? kt + 2 : ntiles - 1;
         if constexpr (PF) {
-            QF_LOAD_B(0, 0)
-            QF_LOAD_A(0, 0)
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ks = 0; ks < QF_KS; ks++) {
-                const int cur = ks & 1, nxt = cur ^ 1;
-                if (ks + 1 < QF_KS) {
-                    QF_LOAD_B(nxt, ks + 1)
-                    QF_LOAD_A(nxt, ks + 1)
-                }
-#pragma unroll
-                for (int j = 0; j < WN; j++)
-#pragma unroll
-                    for (int la = 0; la < LA; la++)
-#pragma unroll
-                        for (int b = 0; b < LB; b++)
-                            acc[j][la + b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[cur][b], bf[cur][j * LA + la],
-                                                                                    acc[j][la + b], 0, 0, 0);
-                // pin the interleave: one next-k-step LDS read issued between consecutive MFMAs of
-                // this k-step (hipcc otherwise sinks every read to just before its use and waits
-                // lgkmcnt(0) in front of every MFMA)
-                if (ks + 1 < QF_KS) {
-#pragma unroll
-                    for (int i = 0; i < WN * LA; i++) {
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read (next k-step)
-                        __builtin_amdgcn_sched_group_barrier(0x008, LB, 0);  // LB MFMAs (this k-step)
-                    }
-                } else {
-                    __builtin_amdgcn_sched_group_barrier(0x008, WN * LA * LB, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);  // k-steps are separate scheduling regions
-            }
+            QF_LOAD_B(1, tile, 1) QF_LOAD_A(1, 0, kt, 1) QF_MFMAS(0) QF_INTERLEAVE()
+            QF_LOAD_B(0, tile, 2) QF_LOAD_A(0, 0, kt, 2) QF_MFMAS(1) QF_INTERLEAVE()
         } else {
 #pragma unroll
-            for (int ks = 0; ks < QF_KS; ks++) {
-                QF_LOAD_A(0, ks)
-#pragma unroll
-                for (int j = 0; j < WN; j++)
-#pragma unroll
-                    for (int la = 0; la < LA; la++) {
-                        const v4i bfr = *(const v4i *)(tile + ((j * QF_KS + ks) * LA + la) * 1024);
-#pragma unroll
-                        for (int b = 0; b < LB; b++)
-                            acc[j][la + b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0][b], bfr, acc[j][la + b], 0, 0, 0);
-                    }
+            for (int ks = 0; ks < 2; ks++) {
+                QF_LOAD_A(0, 0, kt, ks) QF_LOAD_B(0, tile, ks) QF_MFMAS(0)
             }
         }
-        xb = xb_next;
-        __syncthreads();
+        // mid-tile: tile t+1 has landed for everyone, tile t-1's buffer is free
+        QF_T(ta)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        QF_T(tb)
+#ifndef QF_ABL_NOBAR
+        __builtin_amdgcn_s_barrier();
+#endif
+        QF_T(tc)
+        QF_ACC(s_vm, ta, tb) QF_ACC(s_bar, tb, tc)
+        QF_LOAD_AT(1, kt1)
+#ifndef QF_ABL_NODMA
+        QF_STAGE(kt2, buf2)
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PF) {
+            // k-steps 2, 3; the last one prefetches k-step 0 of the next tile
+            QF_LOAD_B(1, tile, 3) QF_LOAD_A(1, 0, kt, 3) QF_MFMAS(0) QF_INTERLEAVE()
+            QF_T(td)
+            QF_WAIT_AT(1, NSR)
+            QF_T(te)
+            QF_ACC(s_at, td, te)
+            QF_LOAD_B(0, tile1, 0) QF_LOAD_A(0, 1, kt1, 0) QF_MFMAS(1) QF_INTERLEAVE()
+        } else {
+#pragma unroll
+            for (int ks = 2; ks < 4; ks++) {
+                QF_LOAD_A(0, 0, kt, ks) QF_LOAD_B(0, tile, ks) QF_MFMAS(0)
+            }
+            QF_WAIT_AT(1, NSR)
+        }
+#pragma unroll
+        for (int i = 0; i < (ATILE ? NAT : 1); i++) at[0][i] = at[1][i];
+        buf = buf1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail DMAs must not outlive the workgroup's LDS
+    QF_T(tl1)
+    QF_ACC(s_loop, tl0, tl1)
 
     // ---- epilogue: recombine digits, reduce, add noise / message, store
     const uint32_t lastrow = a.rows - 1;
@@ -316,6 +382,10 @@ __global__ __launch_bounds__(QF_NW * 64, 2) void qf_gemm_kernel(QfGemmArgs a) {
         for (int r = 0; r < 16; r++) {
             const uint64_t mrow = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (mrow >= a.B) continue;
+#ifdef QF_ABL_NOEPI
+            if (acc[j][0][r] == 0x7fffffff) a.out[mrow] = acc[j][1][r] + acc[j][S - 1][r];
+            continue;
+#endif
             int64_t x = 0;
 #pragma unroll
             for (int s = 0; s < S; s++) x += (int64_t)acc[j][s][r] * (int64_t)a.cs[s];
@@ -324,6 +394,14 @@ __global__ __launch_bounds__(QF_NW * 64, 2) void qf_gemm_kernel(QfGemmArgs a) {
             a.out[mrow * a.rows + krow] = qf_red_i64(x, a.mod);
         }
     }
+#ifdef QF_STAMP
+    QF_T(tl2)
+    QF_ACC(s_epi, tl1, tl2)
+    if (a.dbg && lane == 0) {
+        unsigned long long *d = a.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * QF_NW + wave) * 8;
+        d[0] = s_loop; d[1] = s_vm; d[2] = s_bar; d[3] = s_at; d[4] = s_epi; d[5] = tl0; d[6] = tl2;
+    }
+#endif
 }
 
 // widest column tile (in 32-row blocks) whose accumulators fit comfortably: WN*S*16 <= 192 regs
@@ -335,7 +413,7 @@ static int qf_wn_max(int S) {
 template <int LA, int LB, int WN, bool BITS>
 static int qf_gemm_dispatch_wn(qf_ctx *ctx, const QfGemmArgs &args) {
     constexpr int FRAGS = WN * QF_KS * LA;
-    size_t lds = 2 * (size_t)FRAGS * 1024;
+    size_t lds = 3 * (size_t)FRAGS * 1024;
     static bool attr_done = false;
     if (!attr_done) {
         QF_HIP(ctx, hipFuncSetAttribute((const void *)qf_gemm_kernel<LA, LB, WN, BITS>,
@@ -353,7 +431,11 @@ static int qf_gemm_dispatch_wn(qf_ctx *ctx, const QfGemmArgs &args) {
 template <int LA, int LB, bool BITS>
 static int qf_gemm_dispatch(qf_ctx *ctx, const QfGemmArgs &args) {
     constexpr int S = LA + LB - 1;
-    constexpr int WMAX = (12 / S) < 1 ? 1 : ((12 / S) > 4 ? 4 : (12 / S));
+    // widest tile whose accumulators (16 regs per 32x32 block and digit weight) plus the register
+    // copy of one tile's batch operand stay inside the 256-VGPR budget of 2 waves/SIMD
+    constexpr int ATREGS = BITS ? 0 : (QF_KS * LB <= 8 ? 8 * QF_KS * LB : 0);
+    constexpr int WFIT = ((224 - ATREGS) < 192 ? (224 - ATREGS) : 192) / (S * 16);
+    constexpr int WMAX = WFIT < 1 ? 1 : (WFIT > 4 ? 4 : WFIT);
     // pick the tile width that wastes the fewest padded row blocks, preferring wider tiles
     int best = 1;
     uint32_t best_waste = ~0u;
@@ -382,7 +464,7 @@ int qf_launch_gemm(qf_ctx *ctx, const qf_key *key, const void *X, int x_is_bits,
     a.xbits = x_is_bits ? (const uint8_t *)X : nullptr;
     a.xstride = x_stride;
     a.xplanes = x_is_bits ? nullptr : (const int8_t *)X;
-    a.B = B; a.addend = addend; a.msg = msg; a.out = out; a.mod = key->mod;
+    a.B = B; a.addend = addend; a.msg = msg; a.out = out; a.mod = key->mod; a.dbg = g_qf_dbg;
     // centred 2^(8s) mod q
     uint64_t p = 1 % key->q;
     for (int s = 0; s < 8; s++) {

@@ -1,0 +1,23 @@
+"""Diagnostic: where does a GEMM workgroup spend its cycles?  Needs the QF_STAMP build
+(make -C crypto_amd/csrc STAMP=1).  Prints mean per-wave cycle shares."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from crypto_amd.device import Context, X_BITS
+ctx = Context(0)
+n, m, q, B = 256, 6168, 16777213, 65536
+pk = ctx.sample_uniform(1, 1, 0, (n + 1) * m, q).view(n + 1, m)
+key = ctx.key_upload(pk, q)
+xb = ctx.sample_bits(1, 3, 0, B, m)
+nwaves = (B // 256) * 3 * 8
+dbg = torch.zeros(nwaves * 8, dtype=torch.int64, device="cuda")
+ctx.lib.qf_debug_set_buffer(ctypes.c_void_p(dbg.data_ptr()))
+for _ in range(3):
+    out = ctx.matmul(key, xb, X_BITS, B)
+torch.cuda.synchronize()
+d = dbg.cpu().numpy().reshape(nwaves, 8)
+tot = (d[:, 6] - d[:, 5]).mean()
+print("per-wave cycles: total %.0f loop %.0f vmcnt-wait %.0f barrier %.0f at-wait %.0f epilogue %.0f" %
+      (tot, d[:, 0].mean(), d[:, 1].mean(), d[:, 2].mean(), d[:, 3].mean(), d[:, 4].mean()))
+print("shares of total: loop %.3f vm %.3f bar %.3f at %.3f epi %.3f" % tuple(d[:, i].mean() / tot for i in range(5)))
+print("kernel span cycles (max end - min start): %d" % (d[:, 6].max() - d[:, 5].min()))
