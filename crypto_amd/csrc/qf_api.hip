@@ -5,6 +5,7 @@
 #include <new>
 #include <vector>
 #include "qf_internal.h"
+#include "qf_ring.h"
 
 // ------------------------------------------------------------------ small host number theory
 static uint64_t h_mulmod(uint64_t a, uint64_t b, uint64_t m) { return (unsigned __int128)a * b % m; }
@@ -354,6 +355,7 @@ int qf_ring_create(qf_ctx *ctx, uint32_t n, uint32_t q, qf_ring **out) {
                 return qf_fail(ctx, QF_ERR_DEVICE, "twiddle upload failed");
             }
             r->ntt = 1;
+            r->wave = qf_ring_wave_supported(r->lg) ? 1 : 0;
         }
     }
     *out = r;
@@ -381,13 +383,14 @@ int qf_rkey_upload_dev(qf_ctx *ctx, const qf_ring *ring, const uint32_t *polys_d
     QF_BIND(ctx);
     qf_rkey *k = new (std::nothrow) qf_rkey();
     if (!k) return QF_ERR_DEVICE;
-    k->device = ctx->device; k->n = ring->n; k->q = ring->q; k->npoly = npoly; k->ntt = ring->ntt;
+    k->device = ctx->device; k->n = ring->n; k->q = ring->q; k->npoly = npoly; k->ntt = ring->ntt; k->wave = ring->wave;
     size_t bytes = (size_t)npoly * ring->n * 4;
     if (hipMalloc((void **)&k->coef, bytes) != hipSuccess) { delete k; return qf_fail(ctx, QF_ERR_DEVICE, "hipMalloc(ring key) failed"); }
     // canonicalise through the sampler-free path: copy, then (ntt rings) transform
     if (hipMemcpyAsync(k->coef, polys_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { qf_rkey_destroy(k); return qf_fail(ctx, QF_ERR_DEVICE, "ring key copy failed"); }
     if (ring->ntt) {
-        if (hipMalloc((void **)&k->hat, bytes) != hipSuccess || hipMalloc((void **)&k->hat_p, bytes) != hipSuccess) { qf_rkey_destroy(k); return qf_fail(ctx, QF_ERR_DEVICE, "hipMalloc(ring key) failed"); }
+        if (hipMalloc((void **)&k->hat, ring->wave ? 2 * bytes : bytes) != hipSuccess ||
+            (!ring->wave && hipMalloc((void **)&k->hat_p, bytes) != hipSuccess)) { qf_rkey_destroy(k); return qf_fail(ctx, QF_ERR_DEVICE, "hipMalloc(ring key) failed"); }
         int rc = qf_launch_ntt_forward_keys(ctx, ring, k);
         if (rc) { qf_rkey_destroy(k); return rc; }
     }

@@ -37,6 +37,7 @@ struct qf_ring {
     int device = 0;
     uint32_t n = 0, q = 0, lg = 0;
     int ntt = 0;           // 1 if q prime and 2n | q-1
+    int wave = 0;          // 1 if the wave-per-polynomial kernels (qf_ntt_wave.hip) serve this ring
     QfMod mod;
     // twiddles: psi^bitrev(i) (forward), psi^-bitrev(i) (inverse) and their Shoup companions
     uint32_t *tw = nullptr;   // [4][n]: fw, fw', iw, iw'
@@ -46,10 +47,11 @@ struct qf_ring {
 struct qf_rkey {
     int device = 0;
     uint32_t n = 0, q = 0, npoly = 0;
-    int ntt = 0;
+    int ntt = 0, wave = 0;
     uint32_t *coef = nullptr;  // npoly x n canonical coefficients
-    uint32_t *hat = nullptr;   // npoly x n NTT-domain values (ntt rings only)
-    uint32_t *hat_p = nullptr; // Shoup companions of hat
+    uint32_t *hat = nullptr;   // npoly x n NTT-domain values (ntt rings only); wave rings: npoly x n
+                               // interleaved (value, Shoup companion) pairs in register order
+    uint32_t *hat_p = nullptr; // Shoup companions of hat (null on wave rings)
 };
 
 #define QF_HIP(ctx, call)                                                              \

@@ -13,24 +13,7 @@
 // One launch fuses the whole scheme operation (see MODE_*): operands are read from HBM once,
 // results written once.
 #include "qf_internal.h"
-
-enum { MODE_POLYMUL = 0, MODE_RLPR_ENC = 1, MODE_RLPR_DEC = 2, MODE_FDH = 3, MODE_FWD_ONLY = 4 };
-
-struct QfRingArgs {
-    uint32_t n, lg;
-    QfMod mod;
-    const uint32_t *tw;       // [4][n]
-    uint32_t ninv, ninv_p;
-    uint64_t B;
-    // operands (meaning depends on MODE)
-    const uint32_t *in0, *in1, *in2;  // POLYMUL: a,b | ENC: r,e1,e2 | DEC: u,v | FDH: sigma(i32),-,-
-    const uint8_t *mu;                // ENC: message bits
-    const uint32_t *key, *key_p;      // NTT-domain key polys + Shoup companions (npoly x n)
-    const uint32_t *key_coef;         // coefficient-domain key polys (schoolbook path)
-    uint32_t npoly;
-    uint32_t *out0, *out1;            // POLYMUL: c | ENC: u,v | FDH: t | FWD_ONLY: hat, hat'
-    uint8_t *outb;                    // DEC: packed bits
-};
+#include "qf_ring.h"
 
 #define RING_THREADS 256
 
@@ -315,11 +298,15 @@ static void fill_common(QfRingArgs &a, const qf_ring *ring, uint64_t B) {
     a.ninv = ring->ninv; a.ninv_p = ring->ninv_p; a.B = B;
     a.in0 = a.in1 = a.in2 = nullptr; a.mu = nullptr; a.key = a.key_p = a.key_coef = nullptr;
     a.npoly = 0; a.out0 = a.out1 = nullptr; a.outb = nullptr;
+    a.one_p = (uint32_t)((1ull << 32) / ring->q);
+    a.off32 = (uint32_t)((((1ull << 31) + ring->q - 1) / ring->q) * ring->q);
+    a.u = nullptr; a.ok = nullptr; a.norm_bound = 0;
 }
 template <int MODE>
 static int launch_ring(qf_ctx *ctx, const qf_ring *ring, const QfRingArgs &a) {
     if (a.B == 0) return QF_OK;
     const uint32_t n = ring->n;
+    if (ring->wave) return qf_launch_ring_wave(ctx, ring, MODE, a);
     if (ring->ntt) {
         uint32_t T = n / 2 < RING_THREADS ? n / 2 : RING_THREADS, P = RING_THREADS / T;
         size_t lds = (size_t)2 * P * n * 4;
@@ -364,6 +351,12 @@ int qf_launch_ringlpr_dec(qf_ctx *ctx, const qf_ring *ring, const qf_rkey *sk, c
 int qf_launch_fdh_verify(qf_ctx *ctx, const qf_ring *ring, const qf_rkey *ak, const int32_t *sigma,
                          const uint32_t *u, uint64_t norm_bound, uint64_t B, uint32_t *t, uint8_t *ok) {
     if (B == 0) return QF_OK;
+    if (ring->wave) {  // one fused kernel: transforms, norm, comparison
+        QfRingArgs a; fill_common(a, ring, B);
+        a.in0 = (const uint32_t *)sigma; a.key = ak->hat; a.npoly = ak->npoly; a.out0 = t;
+        a.u = u; a.ok = ok; a.norm_bound = norm_bound;
+        return qf_launch_ring_wave(ctx, ring, MODE_FDH, a);
+    }
     uint32_t *tbuf = t;
     if (!tbuf) {
         int rc = qf_ws_reserve(ctx, (size_t)B * ring->n * 4);

@@ -1,0 +1,398 @@
+// Kernel (b), fast path: negacyclic NTT with ONE WAVE PER POLYNOMIAL, register blocked.
+//
+// n = 2^LG (256..2048): a lane holds R = n/64 coefficients in registers.  A transform is NP =
+// ceil(LG/RB) phases (RB = LG-6 register bits); in phase P the R registers of a lane cover RB
+// index bits, so RB radix-2 stages run entirely in registers, with no memory traffic and no
+// barrier.  Between phases the wave transposes its polynomial through a private LDS buffer
+// (intra-wave: no s_barrier anywhere after the twiddle preload).  n = 1024: 4 + 4 + 2 stages.
+//
+//   phase 0: registers = top RB index bits  -> idx = lane + 64 r: HBM loads/stores are whole
+//            256-byte runs per wave instruction, twiddles are wave-uniform (scalar loads);
+//   middle : registers = next RB bits, lane = the rest; per-lane twiddles from the LDS copy;
+//   last   : registers = the low remaining bits (+ top bits as filler).
+//
+// The forward transform is Cooley-Tukey (natural in, bit-reversed out), the inverse Gentleman-
+// Sande; psi powers are merged into the twiddles (same table as qf_ntt.hip: psi^bitrev(i)), the
+// pointwise stage runs in the last phase's register order, so no permutation is ever applied.
+// Butterflies are Harvey's lazy form when q < 2^30 (values in [0,4q) forward, [0,2q) inverse:
+// 3 multiplies + 6 adds/mins); otherwise every value is kept canonical.  All outputs are
+// canonical residues, bit-identical to the general kernel and the oracle.
+//
+// LDS: twiddle pairs (w, floor(w 2^32/q)) for both directions (16 KiB at n = 1024) + one
+// n-dword transpose buffer per wave; the transposes use an XOR swizzle of the low five address
+// bits (tools/ntt_swizzle_search.py) so that every ds_read_b32/ds_write_b32 is conflict free.
+#include "qf_internal.h"
+#include "qf_ring.h"
+
+#define WV_THREADS 256
+#define WV_WAVES 4
+
+// ---- layouts ---------------------------------------------------------------------------------
+template <int LG, int P>
+struct Ph {
+    static constexpr int RB = LG - 6;
+    static constexpr int R = 1 << RB;
+    static constexpr int raw = LG - (P + 1) * RB;
+    static constexpr bool split = raw < 0;
+    static constexpr int lo = split ? 0 : raw;
+    static constexpr int nst = split ? LG - P * RB : RB;  // stages done in this phase
+    // register bit k -> index bit
+    static constexpr int regbit(int k) { return k < nst ? lo + k : LG - (RB - nst) + (k - nst); }
+    static constexpr uint32_t cpart(int r) {
+        uint32_t v = 0;
+        for (int k = 0; k < RB; k++)
+            if ((r >> k) & 1) v |= 1u << regbit(k);
+        return v;
+    }
+    static __device__ __forceinline__ uint32_t lpart(uint32_t lane) {
+        if (split) return lane << nst;
+        return (lane & ((1u << lo) - 1u)) | ((lane >> lo) << (lo + RB));
+    }
+};
+
+// XOR masks for index bits 5..11 (tools/ntt_swizzle_search.py)
+template <int LG> struct Swz;
+template <> struct Swz<8>  { static constexpr uint32_t m[7] = {6, 31, 1, 0, 0, 0, 0}; };
+template <> struct Swz<9>  { static constexpr uint32_t m[7] = {6, 10, 25, 23, 0, 0, 0}; };
+template <> struct Swz<10> { static constexpr uint32_t m[7] = {26, 31, 22, 26, 22, 0, 0}; };
+template <> struct Swz<11> { static constexpr uint32_t m[7] = {7, 21, 27, 12, 19, 18, 0}; };
+template <int LG>
+__host__ __device__ constexpr uint32_t qf_swz(uint32_t i) {
+    uint32_t x = 0;
+    for (int b = 5; b < LG; b++)
+        if ((i >> b) & 1) x ^= Swz<LG>::m[b - 5];
+    return i ^ x;
+}
+
+// ---- butterflies -----------------------------------------------------------------------------
+template <bool LAZY>
+__device__ __forceinline__ void bf_fwd(uint32_t &X, uint32_t &Y, uint32_t w, uint32_t wp, uint32_t q, uint32_t q2) {
+    uint32_t t = Y * w - __umulhi(Y, wp) * q;  // [0, 2q) for any Y < 2^32
+    if (LAZY) {
+        uint32_t x = min(X, X - q2);           // [0,4q) -> [0,2q)
+        X = x + t;
+        Y = x + q2 - t;
+    } else {
+        t = min(t, t - q);
+        uint32_t x = X, s = x + t, d = x - t;
+        X = min(s, s - q);
+        Y = min(d, d + q);
+    }
+}
+template <bool LAZY>
+__device__ __forceinline__ void bf_inv(uint32_t &X, uint32_t &Y, uint32_t w, uint32_t wp, uint32_t q, uint32_t q2) {
+    if (LAZY) {  // inputs in [0,2q)
+        uint32_t s = X + Y, d = X + q2 - Y;
+        X = min(s, s - q2);
+        Y = d * w - __umulhi(d, wp) * q;
+    } else {
+        uint32_t s = X + Y, d = X - Y;
+        X = min(s, s - q);
+        d = min(d, d + q);
+        uint32_t t = d * w - __umulhi(d, wp) * q;
+        Y = min(t, t - q);
+    }
+}
+
+template <int LG, bool LAZY>
+struct Wv {
+    static constexpr int N = 1 << LG, RB = LG - 6, R = 1 << RB, NP = (LG + RB - 1) / RB;
+
+    // the RB (or fewer) stages of phase P on the registers of one lane
+    template <int P, bool FWD>
+    static __device__ __forceinline__ void stages(uint32_t (&x)[R], uint32_t lane, const uint2 *tw_lds,
+                                                  const uint32_t *tw_g, uint32_t q) {
+        using L = Ph<LG, P>;
+        const uint32_t q2 = 2 * q;
+        const uint32_t lp = L::lpart(lane);
+        constexpr bool uniform = !L::split && L::lo >= 6;  // no lane bit above any stage bit
+#pragma unroll
+        for (int kk = 0; kk < L::nst; kk++) {
+            const int k = FWD ? L::nst - 1 - kk : kk;
+            const int b = L::regbit(k);
+            const uint32_t m = 1u << (LG - 1 - b);
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if ((r >> k) & 1) continue;
+                const int hi = r | (1 << k);
+                uint32_t w, wp;
+                if (uniform) {
+                    const uint32_t ti = m + (L::cpart(r) >> (b + 1));
+                    w = tw_g[ti]; wp = tw_g[N + ti];
+                } else {
+                    const uint2 t2 = tw_lds[m + ((lp | L::cpart(r)) >> (b + 1))];
+                    w = t2.x; wp = t2.y;
+                }
+                if (FWD) bf_fwd<LAZY>(x[r], x[hi], w, wp, q, q2);
+                else bf_inv<LAZY>(x[r], x[hi], w, wp, q, q2);
+            }
+        }
+    }
+
+    template <int PF, int PT>
+    static __device__ __forceinline__ void transpose(uint32_t (&x)[R], uint32_t lane, uint32_t *buf) {
+        const uint32_t wa = qf_swz<LG>(Ph<LG, PF>::lpart(lane)), ra = qf_swz<LG>(Ph<LG, PT>::lpart(lane));
+#pragma unroll
+        for (int r = 0; r < R; r++) buf[wa ^ qf_swz<LG>(Ph<LG, PF>::cpart(r))] = x[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int r = 0; r < R; r++) x[r] = buf[ra ^ qf_swz<LG>(Ph<LG, PT>::cpart(r))];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    template <int P>
+    static __device__ __forceinline__ void fwd_rec(uint32_t (&x)[R], uint32_t lane, uint32_t *buf, const uint2 *twf,
+                                                   const uint32_t *tw_g, uint32_t q) {
+        stages<P, true>(x, lane, twf, tw_g, q);
+        if constexpr (P + 1 < NP) {
+            transpose<P, P + 1>(x, lane, buf);
+            fwd_rec<P + 1>(x, lane, buf, twf, tw_g, q);
+        }
+    }
+    template <int P>
+    static __device__ __forceinline__ void inv_rec(uint32_t (&x)[R], uint32_t lane, uint32_t *buf, const uint2 *twi,
+                                                   const uint32_t *tw_g, uint32_t q) {
+        stages<P, false>(x, lane, twi, tw_g, q);
+        if constexpr (P > 0) {
+            transpose<P, P - 1>(x, lane, buf);
+            inv_rec<P - 1>(x, lane, buf, twi, tw_g, q);
+        }
+    }
+    // x: natural order (idx = lane + 64 r), any value < 4q (lazy) / canonical -> NTT values in the
+    // last phase's register order, in [0,4q) (lazy) / canonical
+    static __device__ __forceinline__ void forward(uint32_t (&x)[R], uint32_t lane, uint32_t *buf, const uint2 *twf,
+                                                   const uint32_t *tw_g, uint32_t q) {
+        fwd_rec<0>(x, lane, buf, twf, tw_g, q);
+    }
+    // x: last-phase order, [0,2q) (lazy) / canonical -> n * (inverse transform), natural order,
+    // same ranges; the caller scales by n^-1
+    static __device__ __forceinline__ void inverse(uint32_t (&x)[R], uint32_t lane, uint32_t *buf, const uint2 *twi,
+                                                   const uint32_t *tw_g_inv, uint32_t q) {
+        inv_rec<NP - 1>(x, lane, buf, twi, tw_g_inv, q);
+    }
+};
+
+// x < 2^32 -> [0,2q) (one_p = floor(2^32/q)); canonical when CANON
+template <bool CANON>
+__device__ __forceinline__ uint32_t wv_red32(uint32_t x, uint32_t one_p, uint32_t q) {
+    uint32_t r = x - __umulhi(x, one_p) * q;
+    return CANON ? min(r, r - q) : r;
+}
+
+template <int LG, int MODE, bool LAZY>
+__global__ __launch_bounds__(WV_THREADS) void qf_ring_wave_kernel(QfRingArgs a) {
+    using W = Wv<LG, LAZY>;
+    constexpr int N = W::N, R = W::R;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint2 *twf = (uint2 *)lds, *twi = twf + N;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint32_t *buf = lds + 4 * N + wave * N;
+    for (uint32_t e = tid; e < (uint32_t)N; e += WV_THREADS) {
+        twf[e] = make_uint2(a.tw[e], a.tw[N + e]);
+        twi[e] = make_uint2(a.tw[2 * N + e], a.tw[3 * N + e]);
+    }
+    __syncthreads();
+    const uint32_t q = a.mod.q, q2 = 2 * q, one_p = a.one_p;
+    const uint32_t *twg_f = a.tw, *twg_i = a.tw + 2 * N;
+    const uint32_t LI = Ph<LG, W::NP - 1>::lpart(lane);  // unused except for documentation of order
+    (void)LI;
+
+    // canonical result of an inverse-transform output scaled by n^-1
+    auto finish = [&](uint32_t v) -> uint32_t {
+        uint32_t t = v * a.ninv - __umulhi(v, a.ninv_p) * q;
+        return min(t, t - q);
+    };
+    auto load_nat = [&](uint32_t(&x)[R], const uint32_t *src) {
+#pragma unroll
+        for (int r = 0; r < R; r++) x[r] = src[lane + 64 * r];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            // the first forward stage needs its "X" inputs below 4q (lazy) / everything canonical
+            if (LAZY) { if (r < R / 2) x[r] = wv_red32<false>(x[r], one_p, q); }
+            else x[r] = wv_red32<true>(x[r], one_p, q);
+        }
+    };
+
+    for (uint64_t item = (uint64_t)blockIdx.x * WV_WAVES + wave; item < a.B; item += (uint64_t)gridDim.x * WV_WAVES) {
+        if constexpr (MODE == MODE_POLYMUL) {
+            uint32_t xa[R], xb[R];
+            load_nat(xa, a.in0 + item * N);
+            load_nat(xb, a.in1 + item * N);
+            W::forward(xa, lane, buf, twf, twg_f, q);
+            W::forward(xb, lane, buf, twf, twg_f, q);
+#pragma unroll
+            for (int r = 0; r < R; r++) xa[r] = qf_mulmod(xa[r], xb[r], a.mod);
+            W::inverse(xa, lane, buf, twi, twg_i, q);
+            uint32_t *dst = a.out0 + item * N;
+#pragma unroll
+            for (int r = 0; r < R; r++) dst[lane + 64 * r] = finish(xa[r]);
+        } else if constexpr (MODE == MODE_FWD_ONLY) {
+            // key preparation: interleaved (value, Shoup companion) pairs in last-phase register order
+            uint32_t x[R];
+            load_nat(x, a.in0 + item * N);
+            W::forward(x, lane, buf, twf, twg_f, q);
+            uint2 *dst = (uint2 *)a.out0 + item * N;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                uint32_t v = x[r];
+                if (LAZY) { v = min(v, v - q2); v = min(v, v - q); }
+                dst[lane + 64 * r] = make_uint2(v, (uint32_t)((((uint64_t)v) << 32) / q));
+            }
+        } else if constexpr (MODE == MODE_RLPR_ENC) {
+            uint32_t xr[R], t[R];
+            load_nat(xr, a.in0 + item * N);
+            W::forward(xr, lane, buf, twf, twg_f, q);
+            // message bits: word j of the row holds coefficients 32j..32j+31
+            const uint32_t *mrow = (const uint32_t *)(a.mu + item * (uint64_t)(N / 8));
+            const uint32_t mword = mrow[lane < (uint32_t)(N / 32) ? lane : 0];
+#pragma unroll 1
+            for (int which = 0; which < 2; which++) {
+                const uint2 *kh = (const uint2 *)a.key + (size_t)which * N;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    uint2 k2 = kh[lane + 64 * r];
+                    uint32_t v = xr[r] * k2.x - __umulhi(xr[r], k2.y) * q;  // [0,2q)
+                    t[r] = LAZY ? v : min(v, v - q);
+                }
+                W::inverse(t, lane, buf, twi, twg_i, q);
+                const uint32_t *noise = (which ? a.in2 : a.in1) + item * N;
+                uint32_t *dst = (which ? a.out1 : a.out0) + item * N;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    uint32_t val = finish(t[r]);
+                    uint32_t e = wv_red32<true>(noise[lane + 64 * r], one_p, q);
+                    val += e; val = min(val, val - q);
+                    if (which) {
+                        uint32_t wlo = __builtin_amdgcn_readlane(mword, (2 * r) % (N / 32));
+                        uint32_t whi = __builtin_amdgcn_readlane(mword, (2 * r + 1) % (N / 32));
+                        uint32_t wsel = lane < 32 ? wlo : whi;
+                        uint32_t add = ((wsel >> (lane & 31)) & 1u) ? a.mod.qhalf : 0u;
+                        val += add; val = min(val, val - q);
+                    }
+                    dst[lane + 64 * r] = val;
+                }
+            }
+        } else if constexpr (MODE == MODE_RLPR_DEC) {
+            uint32_t x[R];
+            load_nat(x, a.in0 + item * N);
+            W::forward(x, lane, buf, twf, twg_f, q);
+            const uint2 *kh = (const uint2 *)a.key;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                uint2 k2 = kh[lane + 64 * r];
+                uint32_t v = x[r] * k2.x - __umulhi(x[r], k2.y) * q;
+                x[r] = LAZY ? v : min(v, v - q);
+            }
+            W::inverse(x, lane, buf, twi, twg_i, q);
+            const uint32_t *vv = a.in1 + item * N;
+            uint32_t myword = 0;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                uint32_t su = finish(x[r]);
+                uint32_t w = qf_submod(wv_red32<true>(vv[lane + 64 * r], one_p, q), su, q);
+                bool bit = qf_ring_dist(w, a.mod.qhalf, q) < qf_ring_dist(w, 0, q);
+                uint64_t m = __ballot(bit);  // coefficients 64r .. 64r+63
+                if (lane == (uint32_t)(2 * r)) myword = (uint32_t)m;
+                if (lane == (uint32_t)(2 * r + 1)) myword = (uint32_t)(m >> 32);
+            }
+            uint32_t *orow = (uint32_t *)(a.outb + item * (uint64_t)(N / 8));
+            if (lane < (uint32_t)(N / 32)) orow[lane] = myword;
+        } else if constexpr (MODE == MODE_FDH) {
+            // t = INTT( sum_j a^_j o NTT(sigma_j mod q) ); ok = [||sigma||^2 <= bound] && [t == u]
+            const int32_t *sig = (const int32_t *)a.in0 + item * (uint64_t)a.npoly * N;
+            uint32_t acc[R], x[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = 0;
+            uint64_t nlo = 0, nhi = 0;  // exact sum of squares, split so nothing overflows
+#pragma unroll 1
+            for (uint32_t j = 0; j < a.npoly; j++) {
+                const int32_t *sj = sig + (size_t)j * N;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    int32_t sv = sj[lane + 64 * r];
+                    uint64_t sq = (uint64_t)((int64_t)sv * (int64_t)sv);
+                    nlo += (uint32_t)sq; nhi += sq >> 32;
+                    // sigma + off32 is in [0, 2^32): off32 = smallest multiple of q >= 2^31
+                    x[r] = LAZY ? wv_red32<false>((uint32_t)sv + a.off32, one_p, q)
+                                : wv_red32<true>((uint32_t)sv + a.off32, one_p, q);
+                }
+                W::forward(x, lane, buf, twf, twg_f, q);
+                const uint2 *kh = (const uint2 *)a.key + (size_t)j * N;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    uint2 k2 = kh[lane + 64 * r];
+                    uint32_t v = x[r] * k2.x - __umulhi(x[r], k2.y) * q;  // [0,2q)
+                    if (LAZY) { uint32_t s = acc[r] + v; acc[r] = min(s, s - q2); }
+                    else { v = min(v, v - q); uint32_t s = acc[r] + v; acc[r] = min(s, s - q); }
+                }
+            }
+            W::inverse(acc, lane, buf, twi, twg_i, q);
+            const uint32_t *urow = a.u + item * N;
+            uint32_t neq = 0;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                uint32_t tv = finish(acc[r]);
+                if (a.out0) a.out0[item * N + lane + 64 * r] = tv;
+                neq |= (tv != wv_red32<true>(urow[lane + 64 * r], one_p, q));
+            }
+            nlo = qf_wave_sum_u64(nlo); nhi = qf_wave_sum_u64(nhi);
+            const uint64_t anyneq = __ballot(neq != 0);
+            if (lane == 0) {
+                uint64_t hi2 = nhi + (nlo >> 32), lo2 = nlo & 0xFFFFFFFFull;
+                bool in_domain = hi2 < (1ull << 32) && ((hi2 << 32) | lo2) <= a.norm_bound;
+                a.ok[item] = (uint8_t)(in_domain && anyneq == 0);
+            }
+        }
+    }
+}
+
+// ---- launcher --------------------------------------------------------------------------------
+template <int LG, int MODE>
+static int wv_launch(qf_ctx *ctx, const qf_ring *ring, const QfRingArgs &a) {
+    constexpr int N = 1 << LG;
+    const size_t lds = (size_t)(4 * N + WV_WAVES * N) * 4;
+    uint64_t blocks = (a.B + WV_WAVES - 1) / WV_WAVES;
+    if (blocks > 256 * 8) blocks = 256 * 8;  // persistent beyond that: waves loop over items
+    const bool lazy = ring->q < (1u << 30);
+    QfTimer t(ctx, &ctx->ms_ntt);
+    if (lazy) {
+        static bool once = false;
+        if (!once) { QF_HIP(ctx, hipFuncSetAttribute((const void *)qf_ring_wave_kernel<LG, MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
+        hipLaunchKernelGGL((qf_ring_wave_kernel<LG, MODE, true>), dim3((unsigned)blocks), dim3(WV_THREADS), lds, ctx->stream, a);
+    } else {
+        static bool once = false;
+        if (!once) { QF_HIP(ctx, hipFuncSetAttribute((const void *)qf_ring_wave_kernel<LG, MODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
+        hipLaunchKernelGGL((qf_ring_wave_kernel<LG, MODE, false>), dim3((unsigned)blocks), dim3(WV_THREADS), lds, ctx->stream, a);
+    }
+    QF_HIP(ctx, hipGetLastError());
+    return QF_OK;
+}
+
+template <int MODE>
+static int wv_dispatch(qf_ctx *ctx, const qf_ring *ring, const QfRingArgs &a) {
+    switch (ring->lg) {
+        case 8: return wv_launch<8, MODE>(ctx, ring, a);
+        case 9: return wv_launch<9, MODE>(ctx, ring, a);
+        case 10: return wv_launch<10, MODE>(ctx, ring, a);
+        case 11: return wv_launch<11, MODE>(ctx, ring, a);
+    }
+    return qf_fail(ctx, QF_ERR_NOTSUP, "wave NTT: degree not instantiated");
+}
+
+bool qf_ring_wave_supported(uint32_t lg) { return lg >= 8 && lg <= 11; }
+
+int qf_launch_ring_wave(qf_ctx *ctx, const qf_ring *ring, int mode, const QfRingArgs &a) {
+    if (a.B == 0) return QF_OK;
+    switch (mode) {
+        case MODE_POLYMUL: return wv_dispatch<MODE_POLYMUL>(ctx, ring, a);
+        case MODE_RLPR_ENC: return wv_dispatch<MODE_RLPR_ENC>(ctx, ring, a);
+        case MODE_RLPR_DEC: return wv_dispatch<MODE_RLPR_DEC>(ctx, ring, a);
+        case MODE_FDH: return wv_dispatch<MODE_FDH>(ctx, ring, a);
+        case MODE_FWD_ONLY: return wv_dispatch<MODE_FWD_ONLY>(ctx, ring, a);
+    }
+    return qf_fail(ctx, QF_ERR_ARG, "wave NTT: bad mode");
+}

@@ -98,7 +98,12 @@ def test_dot_decode(ctx, n, q, B):
 
 
 @pytest.mark.parametrize("n,q,B", [(1024, 1073479681, 37), (16, 2399, 50), (4, 16, 9), (64, 257, 70), (512, 92897729, 6),
-                                   (2, 5, 300), (2048, 1073479681, 3), (256, 7681, 20)])
+                                   (2, 5, 300), (2048, 1073479681, 3), (256, 7681, 20),
+                                   # wave-per-polynomial kernel: every degree it serves, lazy (q < 2^30) and
+                                   # canonical (q >= 2^30) butterflies, ragged batch sizes, one > grid*waves
+                                   (512, 12289, 9), (2048, 12289, 5), (256, 2013265921, 11), (512, 2013265921, 7),
+                                   (1024, 2013265921, 13), (2048, 2013265921, 2), (1024, 12289, 1), (1024, 1073479681, 8200),
+                                   (4096, 1073479681, 2), (128, 257, 10)])
 def test_polymul(ctx, n, q, B):
     a = co.sample_uniform(SEED, 6, 0, B * n, q).reshape(B, n)
     b = co.sample_uniform(SEED, 6, B * n, B * n, q).reshape(B, n)
@@ -107,7 +112,8 @@ def test_polymul(ctx, n, q, B):
     assert np.array_equal(c, co.polymul_batch(a, b, q))
 
 
-@pytest.mark.parametrize("n,q,W,B", [(1024, 1073479681, 2900, 21), (16, 2399, 4, 64), (64, 257 * 512 + 1, 3, 33), (512, 92897729, 200, 5)])
+@pytest.mark.parametrize("n,q,W,B", [(1024, 1073479681, 2900, 21), (16, 2399, 4, 64), (64, 257 * 512 + 1, 3, 33), (512, 92897729, 200, 5),
+                                     (1024, 2013265921, 2900, 9), (256, 7681, 2, 70), (2048, 1073479681, 100, 3), (512, 12289, 2, 6)])
 def test_ringlpr_enc_dec(ctx, n, q, W, B):
     a = co.sample_uniform(SEED, 1, 0, n, q)
     s = co.sample_noise(SEED, 2, 0, n, q, W)
@@ -127,7 +133,8 @@ def test_ringlpr_enc_dec(ctx, n, q, W, B):
     assert np.array_equal(dec, co.ringlpr_dec_batch(s, q, ur, vr))
 
 
-@pytest.mark.parametrize("n,q,B", [(1024, 1073479681, 5), (8, 512, 40), (64, 257, 17)])
+@pytest.mark.parametrize("n,q,B", [(1024, 1073479681, 5), (8, 512, 40), (64, 257, 17), (1024, 2013265921, 3),
+                                   (256, 7681, 9), (512, 12289, 6), (2048, 1073479681, 2)])
 def test_fdh_ring_verify(ctx, n, q, B):
     k = (q - 1).bit_length()
     mbar = k + 2
