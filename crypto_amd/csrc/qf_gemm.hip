@@ -179,12 +179,25 @@ __device__ __forceinline__ v4i qf_expand16(uint32_t w16) {
     return r;
 }
 
-template <int LA, int LB, int WN, bool BITS>
-__global__ __launch_bounds__(QF_NW * 64, (WN * (LA + LB - 1) * 16 <= 48 ? 4 : 2)) void qf_gemm_kernel(QfGemmArgs a) {
+// Pins the instruction interleave of one k-step for hipcc's scheduler: N groups of (1 LDS read,
+// MF MFMAs), with NV vector-memory issues (the LDS-DMA pieces) spread evenly between them.
+template <int I, int N, int NV, int MF>
+struct QfSched {
+    static __device__ __forceinline__ void run() {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
+        constexpr int nv = (I + 1) * NV / N - I * NV / N;
+        if constexpr (nv > 0) __builtin_amdgcn_sched_group_barrier(0x010, nv, 0);
+        if constexpr (I + 1 < N) QfSched<I + 1, N, NV, MF>::run();
+    }
+};
+
+template <int LA, int LB, int WN, int MW, bool BITS>
+__global__ __launch_bounds__(QF_NW * 64, (MW * WN * (LA + LB - 1) * 16 <= 48 ? 4 : 2)) void qf_gemm_kernel(QfGemmArgs a) {
     constexpr int S = LA + LB - 1;
     // prefetch operand fragments one k-step ahead when both register sets fit next to the
     // accumulators (2 waves/SIMD => 256 VGPRs per lane)
-    constexpr bool PF = WN * S * 16 + 8 * (WN * LA + LB) <= 224;
+    constexpr bool PF = MW * WN * S * 16 + 8 * (WN * LA + MW * LB) <= 224;
     constexpr int FRAGS = WN * QF_KS * LA;           // key fragments (1 KiB each) per k-tile
     constexpr int TILE_BYTES = FRAGS * 1024;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 3 * TILE_BYTES
@@ -194,16 +207,18 @@ __global__ __launch_bounds__(QF_NW * 64, (WN * (LA + LB - 1) * 16 <= 48 ? 4 : 2)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
     const uint32_t rb0 = blockIdx.y * WN;
-    const uint64_t mb = (uint64_t)blockIdx.x * QF_NW + wave;  // this wave's message block
+    const uint64_t mb0 = ((uint64_t)blockIdx.x * QF_NW + wave) * MW;  // this wave's first message block
     const uint32_t ntiles = a.ks / QF_KS;
 
-    v16i acc[WN][S];
+    v16i acc[MW][WN][S];
 #pragma unroll
-    for (int j = 0; j < WN; j++)
+    for (int i = 0; i < MW; i++)
 #pragma unroll
-        for (int s = 0; s < S; s++)
+        for (int j = 0; j < WN; j++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[j][s][r] = 0;
+            for (int s = 0; s < S; s++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][s][r] = 0;
 
     // ---- key staging: the k-tile of row block (rb0+j) is QF_KS*LA consecutive 1-KiB fragments in
     // HBM; each wave copies whole fragments straight into LDS with LDS-DMA (no staging registers):
@@ -213,8 +228,9 @@ __global__ __launch_bounds__(QF_NW * 64, (WN * (LA + LB - 1) * 16 <= 48 ? 4 : 2)
     // Every wave issues exactly NSR DMA instructions per tile (a wave whose share runs past the
     // tile re-copies the last fragment: same bytes to the same place), so the stream has no
     // branches and hipcc can count vmcnt exactly around it.
-#define QF_STAGE(kt_, buf_)                                                                          \
-    _Pragma("unroll") for (int i_ = 0; i_ < NSR; i_++) {                                             \
+#define QF_STAGE(kt_, buf_) QF_STAGE_PART(kt_, buf_, 0, NSR)
+#define QF_STAGE_PART(kt_, buf_, i0_, i1_)                                                           \
+    _Pragma("unroll") for (int i_ = (i0_); i_ < (i1_); i_++) {                                       \
         int f_ = wave + i_ * QF_NW;                                                                  \
         f_ = f_ < FRAGS ? f_ : FRAGS - 1;                                                            \
         const int j_ = f_ / (QF_KS * LA), rem_ = f_ % (QF_KS * LA);                                  \
@@ -227,13 +243,18 @@ __global__ __launch_bounds__(QF_NW * 64, (WN * (LA + LB - 1) * 16 <= 48 ? 4 : 2)
             16, 0, 0);                                                                               \
     }
 
-    // ---- batch operand addressing
-    const uint64_t mrow_l = mb * 32 + (lane & 31);                    // message row this lane feeds
-    const uint64_t mrow_c = mrow_l < a.B ? mrow_l : (a.B - 1);        // clamped for loads
-    const uint8_t *xrow = BITS ? a.xbits + mrow_c * a.xstride : nullptr;
+    // ---- batch operand addressing (MW message blocks of 32 per wave)
     const uint64_t nmb = (a.B + 31) / 32;
-    const uint64_t mb_c = mb < nmb ? mb : nmb - 1;
-    const int8_t *xfrag = BITS ? nullptr : a.xplanes + (mb_c * a.ks * LB) * 1024 + (size_t)lane * 16;
+    const uint8_t *xrow[MW];
+    const int8_t *xfrag[MW];
+#pragma unroll
+    for (int i = 0; i < MW; i++) {
+        const uint64_t mrow_l = (mb0 + i) * 32 + (lane & 31);             // message row this lane feeds
+        const uint64_t mrow_c = mrow_l < a.B ? mrow_l : (a.B - 1);        // clamped for loads
+        xrow[i] = BITS ? a.xbits + mrow_c * a.xstride : nullptr;
+        const uint64_t mb_c = mb0 + i < nmb ? mb0 + i : nmb - 1;
+        xfrag[i] = BITS ? nullptr : a.xplanes + (mb_c * a.ks * LB) * 1024 + (size_t)lane * 16;
+    }
 
     // ---- main loop.  Three LDS buffers: the DMA of k-tile t+2 is issued in the middle of tile t
     // (about 1.5 tiles before its first use), so its ~1 us issue-to-landed latency never shows.
@@ -244,29 +265,31 @@ __global__ __launch_bounds__(QF_NW * 64, (WN * (LA + LB - 1) * 16 <= 48 ? 4 : 2)
     // The batch operand of tile t+1 (16 bytes of bits, or KS*LB fragments) is loaded to registers
     // at the same point but BEFORE the DMA is issued: vmcnt retires in order, so a load issued
     // after the DMA could not be consumed until the DMA had landed.
-    constexpr int NAT = BITS ? 1 : QF_KS * LB;   // registers sets (16 B) of one tile's batch operand
-    constexpr bool ATILE = BITS || NAT <= 8;     // whole-tile register prefetch affordable
-    v4i at[2][ATILE ? NAT : 1];
+    constexpr int NAT = BITS ? 1 : QF_KS * LB;        // register sets (16 B) of one tile's batch operand
+    constexpr bool ATILE = BITS || MW * NAT <= 8;     // whole-tile register prefetch affordable
+    v4i at[2][MW][ATILE ? NAT : 1];
     v4i bf[PF ? 2 : 1][WN * LA];
-    v4i af[PF ? 2 : 1][LB];
+    v4i af[PF ? 2 : 1][MW][LB];
     // The tile's batch-operand loads are inline asm: hipcc waits vmcnt(0) for any compiler-visible
     // load while an LDS-DMA is in flight, which would stall on the DMA issued right behind them.
     // QF_WAIT_AT is the matching counted wait (all but the NSR younger DMA instructions retired).
 #define QF_LOAD_AT(set_, kt_)                                                                     \
+    _Pragma("unroll") for (int m_ = 0; m_ < MW; m_++) {                                           \
     if (BITS) {                                                                                   \
         /* bits past the row's stride only ever meet zero-padded key columns: clamp, no branch */ \
         size_t off_ = (size_t)(kt_)*16;                                                           \
         off_ = off_ + 16 <= a.xstride ? off_ : a.xstride - 16;                                    \
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(at[set_][0]) : "v"(xrow + off_) : "memory"); \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(at[set_][m_][0]) : "v"(xrow[m_] + off_) : "memory"); \
     } else if (ATILE) {                                                                           \
         _Pragma("unroll") for (int i_ = 0; i_ < NAT; i_++)                                        \
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(at[set_][i_])                   \
-                         : "v"(xfrag + ((size_t)(kt_)*QF_KS * LB + i_) * 1024) : "memory");       \
-    }
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(at[set_][m_][i_])               \
+                         : "v"(xfrag[m_] + ((size_t)(kt_)*QF_KS * LB + i_) * 1024) : "memory");   \
+    } }
 #define QF_WAIT_AT(set_, n_)                                                                      \
     if (BITS || ATILE) {                                                                          \
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory");                                 \
-        _Pragma("unroll") for (int i_ = 0; i_ < NAT; i_++) asm volatile("" : "+v"(at[set_][i_])); \
+        _Pragma("unroll") for (int m_ = 0; m_ < MW; m_++)                                         \
+        _Pragma("unroll") for (int i_ = 0; i_ < NAT; i_++) asm volatile("" : "+v"(at[set_][m_][i_])); \
     }
 #ifdef QF_ABL_NOLDS
 #define QF_LOAD_B(set_, tile_, ks_)                                                               \
@@ -280,29 +303,36 @@ __global__ __launch_bounds__(QF_NW * 64, (WN * (LA + LB - 1) * 16 <= 48 ? 4 : 2)
             bf[set_][j_ * LA + l_] = *(const v4i *)((tile_) + ((j_ * QF_KS + (ks_)) * LA + l_) * 1024);
 #endif
 #define QF_LOAD_A(set_, atset_, kt_, ks_)                                                         \
+    _Pragma("unroll") for (int m_ = 0; m_ < MW; m_++) {                                           \
     if (BITS) {                                                                                   \
-        const uint32_t w_ = (uint32_t)at[atset_][0][ks_];                                         \
-        af[set_][0] = qf_expand16(h ? (w_ >> 16) : (w_ & 0xFFFFu));                               \
+        const uint32_t w_ = (uint32_t)at[atset_][m_][0][ks_];                                     \
+        af[set_][m_][0] = qf_expand16(h ? (w_ >> 16) : (w_ & 0xFFFFu));                           \
     } else if (ATILE) {                                                                           \
-        _Pragma("unroll") for (int b_ = 0; b_ < LB; b_++) af[set_][b_] = at[atset_][(ks_)*LB + b_]; \
+        _Pragma("unroll") for (int b_ = 0; b_ < LB; b_++) af[set_][m_][b_] = at[atset_][m_][(ks_)*LB + b_]; \
     } else {                                                                                      \
         _Pragma("unroll") for (int b_ = 0; b_ < LB; b_++)                                         \
-            af[set_][b_] = *(const v4i *)(xfrag + (((size_t)(kt_)*QF_KS + (ks_)) * LB + b_) * 1024); \
-    }
+            af[set_][m_][b_] = *(const v4i *)(xfrag[m_] + (((size_t)(kt_)*QF_KS + (ks_)) * LB + b_) * 1024); \
+    } }
 #define QF_MFMAS(set_)                                                                            \
     _Pragma("unroll") for (int j_ = 0; j_ < WN; j_++)                                             \
         _Pragma("unroll") for (int l_ = 0; l_ < LA; l_++)                                         \
-            _Pragma("unroll") for (int b_ = 0; b_ < LB; b_++)                                     \
-                acc[j_][l_ + b_] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[set_][b_], bf[set_][j_ * LA + l_], \
-                                                                         acc[j_][l_ + b_], 0, 0, 0);
+            _Pragma("unroll") for (int m_ = 0; m_ < MW; m_++)                                     \
+                _Pragma("unroll") for (int b_ = 0; b_ < LB; b_++)                                 \
+                    acc[m_][j_][l_ + b_] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[set_][m_][b_], bf[set_][j_ * LA + l_], \
+                                                                                 acc[m_][j_][l_ + b_], 0, 0, 0);
     // pin the interleave: one prefetch LDS read between consecutive MFMA groups (hipcc otherwise
     // sinks every read to just before its use and waits lgkmcnt(0) in front of every MFMA)
 #define QF_INTERLEAVE()                                                                           \
     _Pragma("unroll") for (int i_ = 0; i_ < WN * LA; i_++) {                                      \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                        \
-        __builtin_amdgcn_sched_group_barrier(0x008, LB, 0);                                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, MW * LB, 0);                                  \
     }                                                                                             \
     __builtin_amdgcn_sched_barrier(0);
+
+    // same, with NV_ LDS-DMA issues spread evenly between the MFMA groups: a DMA issue holds its wave
+    // for ~60-180 cycles, and a burst of them right behind the barrier stalls both waves of a SIMD
+    // at once; one at a time, the partner wave's MFMAs cover it
+#define QF_INTERLEAVE_V(NV_) QfSched<0, WN * LA, (NV_), MW * LB>::run(); __builtin_amdgcn_sched_barrier(0);
 
     QF_LOAD_AT(0, 0)
     QF_STAGE(0, 0)
@@ -345,19 +375,29 @@ __global__ __launch_bounds__(QF_NW * 64, (WN * (LA + LB - 1) * 16 <= 48 ? 4 : 2)
         QF_T(tc)
         QF_ACC(s_vm, ta, tb) QF_ACC(s_bar, tb, tc)
         QF_LOAD_AT(1, kt1)
-#ifndef QF_ABL_NODMA
-        QF_STAGE(kt2, buf2)
-#endif
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (PF) {
-            // k-steps 2, 3; the last one prefetches k-step 0 of the next tile
-            QF_LOAD_B(1, tile, 3) QF_LOAD_A(1, 0, kt, 3) QF_MFMAS(0) QF_INTERLEAVE()
+            // k-steps 2, 3; the last one prefetches k-step 0 of the next tile.  The DMA of tile
+            // t+2 is issued piecewise between their MFMAs.
+            constexpr int NSR1 = (NSR + 1) / 2;
+            QF_LOAD_B(1, tile, 3) QF_LOAD_A(1, 0, kt, 3)
+#ifndef QF_ABL_NODMA
+            QF_STAGE_PART(kt2, buf2, 0, NSR1)
+#endif
+            QF_MFMAS(0) QF_INTERLEAVE_V(NSR1)
             QF_T(td)
-            QF_WAIT_AT(1, NSR)
+            QF_WAIT_AT(1, NSR1)
             QF_T(te)
             QF_ACC(s_at, td, te)
-            QF_LOAD_B(0, tile1, 0) QF_LOAD_A(0, 1, kt1, 0) QF_MFMAS(1) QF_INTERLEAVE()
+            QF_LOAD_B(0, tile1, 0) QF_LOAD_A(0, 1, kt1, 0)
+#ifndef QF_ABL_NODMA
+            QF_STAGE_PART(kt2, buf2, NSR1, NSR)
+#endif
+            QF_MFMAS(1) QF_INTERLEAVE_V(NSR - NSR1)
         } else {
+#ifndef QF_ABL_NODMA
+            QF_STAGE(kt2, buf2)
+#endif
 #pragma unroll
             for (int ks = 2; ks < 4; ks++) {
                 QF_LOAD_A(0, 0, kt, ks) QF_LOAD_B(0, tile, ks) QF_MFMAS(0)
@@ -365,7 +405,9 @@ __global__ __launch_bounds__(QF_NW * 64, (WN * (LA + LB - 1) * 16 <= 48 ? 4 : 2)
             QF_WAIT_AT(1, NSR)
         }
 #pragma unroll
-        for (int i = 0; i < (ATILE ? NAT : 1); i++) at[0][i] = at[1][i];
+        for (int m = 0; m < MW; m++)
+#pragma unroll
+            for (int i = 0; i < (ATILE ? NAT : 1); i++) at[0][m][i] = at[1][m][i];
         buf = buf1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail DMAs must not outlive the workgroup's LDS
@@ -375,24 +417,27 @@ __global__ __launch_bounds__(QF_NW * 64, (WN * (LA + LB - 1) * 16 <= 48 ? 4 : 2)
     // ---- epilogue: recombine digits, reduce, add noise / message, store
     const uint32_t lastrow = a.rows - 1;
 #pragma unroll
+    for (int i = 0; i < MW; i++) {
+#pragma unroll
     for (int j = 0; j < WN; j++) {
         const uint32_t krow = (rb0 + j) * 32 + (lane & 31);
         if (rb0 + j >= a.rb || krow >= a.rows) continue;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const uint64_t mrow = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const uint64_t mrow = (mb0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (mrow >= a.B) continue;
 #ifdef QF_ABL_NOEPI
-            if (acc[j][0][r] == 0x7fffffff) a.out[mrow] = acc[j][1][r] + acc[j][S - 1][r];
+            if (acc[i][j][0][r] == 0x7fffffff) a.out[mrow] = acc[i][j][1][r] + acc[i][j][S - 1][r];
             continue;
 #endif
             int64_t x = 0;
 #pragma unroll
-            for (int s = 0; s < S; s++) x += (int64_t)acc[j][s][r] * (int64_t)a.cs[s];
+            for (int s = 0; s < S; s++) x += (int64_t)acc[i][j][s][r] * (int64_t)a.cs[s];
             if (a.addend) x += (int64_t)a.addend[mrow * a.rows + krow];
             if (a.msg && krow == lastrow && (a.msg[mrow] & 1)) x += (int64_t)a.mod.qhalf;
             a.out[mrow * a.rows + krow] = qf_red_i64(x, a.mod);
         }
+    }
     }
 #ifdef QF_STAMP
     QF_T(tl2)
@@ -410,48 +455,59 @@ static int qf_wn_max(int S) {
     return w < 1 ? 1 : (w > 4 ? 4 : w);
 }
 
-template <int LA, int LB, int WN, bool BITS>
+template <int LA, int LB, int WN, int MW, bool BITS>
 static int qf_gemm_dispatch_wn(qf_ctx *ctx, const QfGemmArgs &args) {
     constexpr int FRAGS = WN * QF_KS * LA;
     size_t lds = 3 * (size_t)FRAGS * 1024;
     static bool attr_done = false;
     if (!attr_done) {
-        QF_HIP(ctx, hipFuncSetAttribute((const void *)qf_gemm_kernel<LA, LB, WN, BITS>,
+        QF_HIP(ctx, hipFuncSetAttribute((const void *)qf_gemm_kernel<LA, LB, WN, MW, BITS>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    uint64_t nmsgtiles = (args.B + 32 * QF_NW - 1) / (32 * QF_NW);
+    uint64_t nmsgtiles = (args.B + 32 * QF_NW * MW - 1) / (32 * QF_NW * MW);
     dim3 grid((unsigned)nmsgtiles, (args.rb + WN - 1) / WN), block(QF_NW * 64);
     QfTimer t(ctx, &ctx->ms_gemm);
-    hipLaunchKernelGGL((qf_gemm_kernel<LA, LB, WN, BITS>), grid, block, lds, ctx->stream, args);
+    hipLaunchKernelGGL((qf_gemm_kernel<LA, LB, WN, MW, BITS>), grid, block, lds, ctx->stream, args);
     QF_HIP(ctx, hipGetLastError());
     return QF_OK;
 }
 
+// Wave tile = MW*32 messages x WN*32 key rows; its accumulators (16 registers per 32x32 block and
+// digit weight) must leave room for operand fragments inside the 256-VGPR budget of 2 waves/SIMD.
 template <int LA, int LB, bool BITS>
 static int qf_gemm_dispatch(qf_ctx *ctx, const QfGemmArgs &args) {
     constexpr int S = LA + LB - 1;
-    // widest tile whose accumulators (16 regs per 32x32 block and digit weight) plus the register
-    // copy of one tile's batch operand stay inside the 256-VGPR budget of 2 waves/SIMD
     constexpr int ATREGS = BITS ? 0 : (QF_KS * LB <= 8 ? 8 * QF_KS * LB : 0);
-    constexpr int WFIT = ((224 - ATREGS) < 192 ? (224 - ATREGS) : 192) / (S * 16);
+    constexpr int BUDGET = (224 - ATREGS) < 192 ? (224 - ATREGS) : 192;
+    constexpr int WFIT = BUDGET / (S * 16);
     constexpr int WMAX = WFIT < 1 ? 1 : (WFIT > 4 ? 4 : WFIT);
-    // pick the tile width that wastes the fewest padded row blocks, preferring wider tiles
+    // pick the tile width by cost = padded row blocks x (1 + 0.3/w): a wider tile re-uses each
+    // batch fragment for more MFMAs (measured: LPR n=1024 is 30% faster at w=2 than at w=1 although
+    // 33 row blocks pad to 34), a narrower one wastes fewer padded rows (Regev: 9 blocks -> w=3)
     int best = 1;
-    uint32_t best_waste = ~0u;
+    double best_cost = 1e30;
     for (int w = WMAX; w >= 1; w--) {
-        uint32_t tiles = (args.rb + w - 1) / w, waste = tiles * w - args.rb;
-        if (waste < best_waste) { best_waste = waste; best = w; }
+        uint32_t tiles = (args.rb + w - 1) / w;
+        double cost = (double)tiles * w * (1.0 + 0.3 / w);
+        if (cost < best_cost) { best_cost = cost; best = w; }
     }
+    int mw = 1;
     if (const char *e = getenv("QF_GEMM_WN")) {  // experiments only
         int w = atoi(e);
         if (w >= 1 && w <= WMAX) best = w;
     }
+    if (const char *e = getenv("QF_GEMM_MW")) mw = atoi(e);
+    constexpr bool M2W2 = 2 * 2 * S * 16 <= BUDGET, M2W1 = 2 * 1 * S * 16 <= BUDGET;
+    if (mw == 2) {
+        if (best >= 2) { if constexpr (M2W2) return qf_gemm_dispatch_wn<LA, LB, 2, 2, BITS>(ctx, args); }
+        if constexpr (M2W1) return qf_gemm_dispatch_wn<LA, LB, 1, 2, BITS>(ctx, args);
+    }
     switch (best) {
-        case 1: return qf_gemm_dispatch_wn<LA, LB, 1, BITS>(ctx, args);
-        case 2: if constexpr (WMAX >= 2) return qf_gemm_dispatch_wn<LA, LB, 2, BITS>(ctx, args); break;
-        case 3: if constexpr (WMAX >= 3) return qf_gemm_dispatch_wn<LA, LB, 3, BITS>(ctx, args); break;
-        case 4: if constexpr (WMAX >= 4) return qf_gemm_dispatch_wn<LA, LB, 4, BITS>(ctx, args); break;
+        case 1: return qf_gemm_dispatch_wn<LA, LB, 1, 1, BITS>(ctx, args);
+        case 2: if constexpr (WMAX >= 2) return qf_gemm_dispatch_wn<LA, LB, 2, 1, BITS>(ctx, args); break;
+        case 3: if constexpr (WMAX >= 3) return qf_gemm_dispatch_wn<LA, LB, 3, 1, BITS>(ctx, args); break;
+        case 4: if constexpr (WMAX >= 4) return qf_gemm_dispatch_wn<LA, LB, 4, 1, BITS>(ctx, args); break;
     }
     return qf_fail(ctx, QF_ERR_NOTSUP, "gemm: no tile configuration");
 }

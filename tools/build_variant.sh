@@ -1,0 +1,15 @@
+#!/bin/bash
+# Diagnostic builds of libqfgpu: tools/build_variant.sh NAME [-DQF_STAMP] [-DQF_ABL_...]  -> tools/abl/libqfgpu_NAME.so
+set -e
+name=$1; shift
+root=$(cd "$(dirname "$0")/.." && pwd)
+tmp=$(mktemp -d)
+for f in qf_api qf_gemm qf_matvec qf_ntt qf_ntt_wave qf_sampler; do
+  flags=""
+  [ $f = qf_gemm ] && flags="$*"
+  /opt/rocm/bin/hipcc $flags -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -c $root/crypto_amd/csrc/$f.hip -o $tmp/$f.o &
+done
+wait
+mkdir -p $root/tools/abl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/tools/abl/libqfgpu_$name.so $tmp/*.o
+rm -rf $tmp
