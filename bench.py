@@ -30,6 +30,23 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 SEED = 0x5146414C4C
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r1")
+
+
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of a kernel from the committed PMC passes (tools/profile_round.sh:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench, FETCH doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  None when no profile of this tree is committed."""
+    try:
+        t = json.load(open(os.path.join(PROFILE_DIR, "traffic.json")))
+    except (OSError, ValueError):
+        return None
+    for k, v in t.items():
+        if k.startswith(kernel_prefix) and v.get("fetch_bytes_per_launch_x2") is not None and v.get("write_bytes_per_launch") is not None:
+            return v["fetch_bytes_per_launch_x2"] + v["write_bytes_per_launch"]
+    return None
+
+
 INT8_PEAK_TOPS = 5033.0   # 2048 int8 op/clk/SIMD x 1024 SIMDs x 2.4 GHz (MI355X_MICROARCH.md "Matrix cores": I8 = 2x BF16)
 HBM_PEAK_GBS = 8000.0
 
@@ -145,10 +162,12 @@ def main():
         "config": {"workload": "Regev enc+dec round trip (BASELINE config 2)", "n": n, "m": m, "q": q,
                    "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"batch-shard x{world}",
                    "key_broadcast_ms": t_bcast * 1e3},
-        "roofline": {"kernel": "qf_gemm_kernel<3,1,3,bits>", "bound": "mfma", "achieved": achieved_tops,
+        "roofline": {"kernel": "qf_gemm_kernel<3,1,3,1,bits>", "bound": "mfma", "achieved": achieved_tops,
                      "peak": INT8_PEAK_TOPS, "unit": "TFLOP/s", "frac": achieved_tops / INT8_PEAK_TOPS,
-                     "traffic": None, "launch_ms": gemm_ms,
-                     "note": "int8 multiply-accumulates counted as 2 ops; algorithmic ops = 2*La*Lb*(n+1)*m per encryption"},
+                     "traffic": pmc_traffic("qf_gemm_kernel") if B == 65536 else None, "launch_ms": gemm_ms,
+                     "note": "int8 multiply-accumulates counted as 2 ops; algorithmic ops = 2*La*Lb*(n+1)*m per encryption; "
+                             "traffic = HBM bytes per launch from the committed PMC passes (profiles/r1/traffic.json); "
+                             "sustained bare-MFMA rate on this data (tools/ubench_mfma): 3.4-3.65 POP/s at the 1.7-1.8 GHz the chip holds"},
         "decode": {"kernel": "qf_dot_decode_kernel", "bound": "hbm", "launch_ms": dec_ms,
                    "achieved": B * (n + 1) * 4 / (dec_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": B * (n + 1) * 4 / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
@@ -182,9 +201,10 @@ def main():
         gbs = Br * 3 * 4 * nr / (ms * 1e-3) / 1e9
         out["ring_polymul"] = {"metric": "ring-polymuls/sec (n=1024, q=2^30-2^18+1)", "value": rate, "unit": "polymuls/s",
                                "batch_per_gpu": Br, "launch_ms": ms,
-                               "roofline": {"kernel": "qf_ring_ntt_kernel<polymul>", "bound": "hbm", "achieved": gbs,
+                               "roofline": {"kernel": "qf_ring_wave_kernel<10,polymul,lazy>", "bound": "hbm", "achieved": gbs,
                                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                            "traffic": None, "note": "algorithmic bytes = 12,288 per product (2 in, 1 out)"}}
+                                            "traffic": pmc_traffic("qf_ring_wave_kernel<10, 0") if Br == 65536 else None,
+                                            "note": "algorithmic bytes = 12,288 per product (2 in, 1 out)"}}
 
     # ---- CPU baseline (rank 0, single-GPU run only) -----------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -344,7 +364,7 @@ def other_workloads(args):
         gbs = B * bytes_per / (ms * 1e-3) / 1e9
         out.update({"scaling": "strong", "ms_per_step": el / args.steps * 1e3, "dtype": "u32 (exact Z_q, Shoup NTT)",
                     "config": {"workload": f"{wl} n=1024 (BASELINE config 5)", "n": n, "q": q, "global_batch": Btot},
-                    "roofline": {"kernel": "qf_ring_ntt_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                    "roofline": {"kernel": "qf_ring_wave_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "launch_ms": ms}})
     elif wl == "matvec":
         # single-message SIS hash, matrix cache-cold: rotate over > 256 MiB of distinct keys
@@ -366,7 +386,7 @@ def other_workloads(args):
                     "value": world * max(args.steps, nkeys * 2) / el, "unit": "hashes/s", "scaling": "weak",
                     "ms_per_step": ms, "dtype": "u32 (exact Z_q)",
                     "config": {"workload": "SIS mat-vec n=512 m=11776, 14 keys = 338 MB rotated", "n": n, "m": m, "q": q},
-                    "roofline": {"kernel": "qf_matvec_partial+finish", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                    "roofline": {"kernel": "qf_matvec_rows", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "launch_ms": ms}})
     if rank == 0:
         print(json.dumps(out))

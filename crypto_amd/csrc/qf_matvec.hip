@@ -65,6 +65,29 @@ __global__ void qf_matvec_finish(const Acc2 *__restrict__ partial, uint32_t n, u
     y[i] = acc_finish(lo, hi, mod);
 }
 
+// y = A*x in ONE launch when every row starts 16-byte aligned: a workgroup streams a whole row
+// (all its loads are independent and issued back to back), reduces it and writes the canonical
+// residue -- no partial-sum buffer, no second kernel.
+__global__ __launch_bounds__(MV_BLOCK) void qf_matvec_rows(const uint32_t *__restrict__ A, uint32_t cols,
+                                                           const uint32_t *__restrict__ x, QfMod mod,
+                                                           uint32_t *__restrict__ y) {
+    __shared__ Acc2 sm[MV_BLOCK / 64];
+    const uint32_t row = blockIdx.x;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 *a = (const u32x4 *)(A + (size_t)row * cols);
+    const u32x4 *xv4 = (const u32x4 *)x;
+    const uint32_t nv = cols >> 2;  // cols % 4 == 0 (checked by the launcher)
+    Acc2 acc = {0, 0};
+#pragma unroll 4
+    for (uint32_t i = threadIdx.x; i < nv; i += MV_BLOCK) {
+        const u32x4 av = __builtin_nontemporal_load(a + i), xv = xv4[i];
+        acc_mad(acc, av.x, xv.x); acc_mad(acc, av.y, xv.y);
+        acc_mad(acc, av.z, xv.z); acc_mad(acc, av.w, xv.w);
+    }
+    Acc2 t = block_sum(acc, sm);
+    if (threadIdx.x == 0) y[row] = acc_finish(t.lo, t.hi, mod);
+}
+
 // y^t = x^t*A : grid (column tiles of 1024, row chunks); thread owns 4 adjacent columns
 #define VM_ROWS 64
 __global__ __launch_bounds__(MV_BLOCK) void qf_vecmat_partial(const uint32_t *__restrict__ A,
@@ -101,6 +124,13 @@ __global__ void qf_vecmat_finish(const Acc2 *__restrict__ partial, uint32_t cols
 }
 
 int qf_launch_matvec(qf_ctx *ctx, const qf_key *key, const uint32_t *x, uint32_t *y) {
+    if (key->rows >= 128 && (key->cols & 3) == 0 && (((uintptr_t)key->u32) & 15) == 0 && (((uintptr_t)x) & 15) == 0) {
+        QfTimer t(ctx, &ctx->ms_matvec);
+        hipLaunchKernelGGL(qf_matvec_rows, dim3(key->rows), dim3(MV_BLOCK), 0, ctx->stream, key->u32, key->cols, x,
+                           key->mod, y);
+        QF_HIP(ctx, hipGetLastError());
+        return QF_OK;
+    }
     uint32_t nchunk = (key->cols + MV_CHUNK - 1) / MV_CHUNK;
     int rc = qf_ws2_reserve(ctx, (size_t)key->rows * nchunk * sizeof(Acc2));
     if (rc) return rc;
@@ -150,7 +180,7 @@ __global__ __launch_bounds__(256) void qf_dot_decode_kernel(const uint32_t *__re
 int qf_launch_dot_decode(qf_ctx *ctx, const uint32_t *w, uint32_t n, const QfMod &mod, const uint32_t *C,
                          uint64_t B, uint8_t *bits) {
     uint64_t blocks = (B + 3) / 4;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks > 256 * 64) blocks = 256 * 64;
     if (blocks == 0) return QF_OK;
     QfTimer t(ctx, &ctx->ms_decode);
     hipLaunchKernelGGL(qf_dot_decode_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, w, n, mod, C, B, bits);
