@@ -52,6 +52,7 @@ SYMBOLS = {
     "qf_matvec_modq_dev": (_i, [_vp, _vp, _vp, _vp]),
     "qf_vecmat_modq_dev": (_i, [_vp, _vp, _vp, _vp]),
     "qf_dot_decode_dev": (_i, [_vp, _vp, _u32, _u32, _vp, _u64, _vp]),
+    "qf_hash_to_mat_zq_sha256_dev": (_i, [_vp, _vp, _vp, _u64, _u32, _u32, _u32, _vp]),
     "qf_ring_create": (_i, [_vp, _u32, _u32, _pp]),
     "qf_ring_destroy": (None, [_vp]),
     "qf_ring_info": (_i, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_i)]),

@@ -57,3 +57,10 @@ class HashMatPolynomialRingZq:
             raise NotImplementedError("only the 1x1 target used by FDH::init_gpv_ring is on the hot path")
         n, q = self.modulus.get_degree(), self.modulus.get_q()
         return hash_to_mat_zq_sha256(m, n, 1, q).entries.reshape(-1)
+
+    def hash_batch_dev(self, ctx, messages):
+        """The same hash for many strings on the device (qf_hash_to_mat_zq_sha256_dev): (B, n) residues
+        resident in HBM, ready to be the `u` operand of the verification kernel."""
+        if (self.rows, self.cols) != (1, 1):
+            raise NotImplementedError("only the 1x1 target used by FDH::init_gpv_ring is on the hot path")
+        return ctx.hash_to_mat_zq_sha256(messages, self.modulus.get_degree(), 1, self.modulus.get_q())

@@ -40,9 +40,9 @@ class FDH:
         out = [False] * B
         if not idx:
             return out
-        u = np.stack([self.hash.hash(messages[i]) for i in idx]).astype(np.uint32)
+        u = self.hash.hash_batch_dev(psf.ctx, [messages[i] for i in idx])   # SHA-256 on the device
         key = psf.ring.key(np.asarray(pk, np.uint32).reshape(psf.mbar, psf.gp.n))
-        ok = psf.ring.fdh_verify(key, psf._sigma_tensor([sigmas[i] for i in idx]), psf.ctx.to_dev_u32(u), psf.norm_bound())
+        ok = psf.ring.fdh_verify(key, psf._sigma_tensor([sigmas[i] for i in idx]), u, psf.norm_bound())
         for i, v in zip(idx, psf.ctx.to_host_u8(ok)):
             out[i] = bool(v)
         return out

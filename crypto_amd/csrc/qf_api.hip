@@ -471,6 +471,18 @@ int qf_fdh_ring_verify_dev(qf_ctx *ctx, const qf_ring *ring, const qf_rkey *a, c
     return qf_launch_fdh_verify(ctx, ring, a, sigma_dev, u_dev, norm_bound, B, t_dev, ok_dev);
 }
 
+int qf_hash_to_mat_zq_sha256_dev(qf_ctx *ctx, const uint8_t *msgs_dev, const uint64_t *offsets_dev, uint64_t B,
+                                 uint32_t rows, uint32_t cols, uint32_t q, uint32_t *out_dev) {
+    if (!ctx) return QF_ERR_ARG;
+    if (B == 0) return QF_OK;
+    if (!offsets_dev || !out_dev) return qf_fail(ctx, QF_ERR_ARG, "hash: null operand");
+    if (rows == 0 || cols == 0) return qf_fail(ctx, QF_ERR_DIM, "hash: number of rows and columns must be positive");
+    int rc = check_q(ctx, q);
+    if (rc) return rc;
+    QF_BIND(ctx);
+    return qf_launch_hash_to_zq(ctx, msgs_dev, offsets_dev, B, rows, cols, qf_make_mod(q), out_dev);
+}
+
 // ------------------------------------------------------------------ generator
 static uint64_t gen_base(uint64_t seed, uint32_t stream) { return seed ^ ((uint64_t)stream << 48); }
 int qf_sample_uniform_dev(qf_ctx *ctx, uint64_t seed, uint32_t stream, uint64_t first, uint64_t count, uint32_t q, uint32_t *out_dev) {

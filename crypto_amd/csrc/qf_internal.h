@@ -103,6 +103,10 @@ int qf_launch_ringlpr_dec(qf_ctx *ctx, const qf_ring *ring, const qf_rkey *sk, c
 int qf_launch_fdh_verify(qf_ctx *ctx, const qf_ring *ring, const qf_rkey *a, const int32_t *sigma,
                          const uint32_t *u, uint64_t norm_bound, uint64_t B, uint32_t *t, uint8_t *ok);
 
+// qf_sha256.hip
+int qf_launch_hash_to_zq(qf_ctx *ctx, const uint8_t *msgs, const uint64_t *offs, uint64_t B, uint32_t rows,
+                         uint32_t cols, const QfMod &mod, uint32_t *out);
+
 // timing helpers: bracket the dominant kernel of an op with events when ctx->timing is set
 struct QfTimer {
     qf_ctx *ctx;

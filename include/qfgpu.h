@@ -165,6 +165,16 @@ int qf_fdh_ring_verify_dev(qf_ctx *ctx, const qf_ring *ring, const qf_rkey *a, c
                            const uint32_t *u_dev, uint64_t norm_bound, uint64_t B, uint32_t *t_dev,
                            uint8_t *ok_dev);
 
+/* Hash-to-Z_q^{rows x cols} for B strings (the caller step of FDH::vfy, signature/fdh.rs:119):
+ *   out[b][i*cols + j] = hash_to_mat_zq_sha256(msg_b, rows, cols, q)[i][j]     hash/sha256.rs:110-133
+ *                      = int(sha256_hex("0 {q} {i} {j} {rows} {cols} {msg_b}"), 16) mod q   (:65-83)
+ * With rows = n, cols = 1 this is HashMatPolynomialRingZq{rows:1, cols:1}.hash (hash/sha256.rs:249-256,
+ * fdh/gpv_ring.rs:78-82): out[b][r] = coefficient r of the hashed ring element, i.e. the u_dev
+ * operand of qf_fdh_ring_verify_dev.  msgs_dev: the UTF-8 bytes of all strings back to back;
+ * offsets_dev: B+1 byte offsets (string b = msgs[offsets[b] .. offsets[b+1])). */
+int qf_hash_to_mat_zq_sha256_dev(qf_ctx *ctx, const uint8_t *msgs_dev, const uint64_t *offsets_dev, uint64_t B,
+                                 uint32_t rows, uint32_t cols, uint32_t q, uint32_t *out_dev);
+
 /* ------------------------------------------------------------------ seeded generator
  * The reference samples from an unseeded RNG (e.g. regev.rs:352-364,401), so parity is defined
  * on inputs produced by this counter-mode SplitMix64 generator, implemented identically in

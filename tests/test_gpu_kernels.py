@@ -153,3 +153,24 @@ def test_fdh_ring_verify(ctx, n, q, B):
     assert np.array_equal(ctx.to_host_u32(t), t_ref)
     assert np.array_equal(ctx.to_host_u8(ok), ok_ref)
     assert ok_ref[1] == 0 and ok_ref[0] == 1
+
+
+def test_hash_to_mat_zq_sha256_kats(ctx):
+    """construction/hash/sha256.rs:104,300-332 known answers, through the device kernel."""
+    got = ctx.to_host_u32(ctx.hash_to_mat_zq_sha256(["Hello World!"], 2, 2, 7)).reshape(2, 2)
+    assert got.tolist() == [[6, 3], [5, 2]]
+    got = ctx.to_host_u32(ctx.hash_to_mat_zq_sha256(["Hello World!"], 2, 2, 256)).reshape(2, 2)
+    assert got.tolist() == [[159, 26], [249, 141]]
+    got = ctx.to_host_u32(ctx.hash_to_mat_zq_sha256(["qfall"], 2, 2, 16)).reshape(2, 2)
+    assert got.tolist() == [[3, 12], [9, 12]]
+
+
+@pytest.mark.parametrize("rows,cols,q", [(1024, 1, 1073479681), (8, 1, 512), (5, 3, 2147483629), (64, 1, 257)])
+def test_hash_to_mat_zq_sha256_vs_oracle(ctx, rows, cols, q):
+    """Ragged messages: empty, one block, the 55/56/64-byte padding edges, multi-block, non-ASCII."""
+    from oracle import pyoracle as po
+    msgs = ["", "a", "x" * 20, "y" * 55, "z" * 56, "w" * 64, "Hello World! " * 40, "gr\u00fc\u00dfe \u2713", "m" * 119, "k" * 120]
+    got = ctx.to_host_u32(ctx.hash_to_mat_zq_sha256(msgs, rows, cols, q))
+    for b, m in enumerate(msgs):
+        ref = np.array(po.hash_to_mat_zq(m, rows, cols, q), dtype=np.uint64).reshape(-1)
+        assert np.array_equal(got[b].astype(np.uint64), ref), (b, m[:10])

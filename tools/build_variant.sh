@@ -4,7 +4,7 @@ set -e
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 tmp=$(mktemp -d)
-for f in qf_api qf_gemm qf_matvec qf_ntt qf_ntt_wave qf_sampler; do
+for f in qf_api qf_gemm qf_matvec qf_ntt qf_ntt_wave qf_sampler qf_sha256; do
   flags=""
   [ $f = qf_gemm ] && flags="$*"
   /opt/rocm/bin/hipcc $flags -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -c $root/crypto_amd/csrc/$f.hip -o $tmp/$f.o &
