@@ -161,26 +161,67 @@ int qf_launch_vecmat(qf_ctx *ctx, const qf_key *key, const uint32_t *x, uint32_t
     return QF_OK;
 }
 
-// Batched decryption: one wave per ciphertext, lanes stride over the n+1 entries.
+// Batched decryption: a wave handles DEC_U ciphertexts per iteration (all their loads in flight
+// together), lanes stride over the n entries.  Each lane folds its split 64-bit sums to a canonical
+// residue once; the wave sum is then taken mod q with DPP adds inside each row of 16 lanes (no LDS
+// traffic) and four scalar reads.
+#define DEC_U 4
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_addmod(uint32_t v, uint32_t q) {
+    uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+    uint32_t s = v + o;  // both < q < 2^31
+    return min(s, s - q);
+}
+__device__ __forceinline__ uint32_t wave_sum_modq(uint32_t v, uint32_t q) {
+    v = dpp_addmod<0xB1>(v, q);   // quad_perm [1,0,3,2]
+    v = dpp_addmod<0x4E>(v, q);   // quad_perm [2,3,0,1]
+    v = dpp_addmod<0x141>(v, q);  // row_half_mirror: the other quad of each 8
+    v = dpp_addmod<0x140>(v, q);  // row_mirror: the other half of each row of 16
+    uint32_t r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    uint32_t r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    uint32_t a = r0 + r1; a = min(a, a - q);
+    uint32_t b = r2 + r3; b = min(b, b - q);
+    a += b;
+    return min(a, a - q);
+}
 __global__ __launch_bounds__(256) void qf_dot_decode_kernel(const uint32_t *__restrict__ w, uint32_t n,
                                                             QfMod mod, const uint32_t *__restrict__ C,
                                                             uint64_t B, uint8_t *__restrict__ bits) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t b = wave; b < B; b += nwaves) {
-        const uint32_t *c = C + b * (n + 1);
-        Acc2 acc = {0, 0};
-        for (uint32_t i = lane; i < n; i += 64) acc_mad(acc, w[i], c[i]);
-        if (lane == 0) acc.lo += c[n];
-        uint64_t lo = qf_wave_sum_u64(acc.lo), hi = qf_wave_sum_u64(acc.hi);
-        if (lane == 0) bits[b] = (uint8_t)qf_decide_bit(acc_finish(lo, hi, mod), mod);
+    const uint32_t stride = n + 1;
+    for (uint64_t b0 = wave * DEC_U; b0 < B; b0 += nwaves * DEC_U) {
+        const uint32_t *c[DEC_U];
+        Acc2 acc[DEC_U];
+#pragma unroll
+        for (int u = 0; u < DEC_U; u++) {
+            const uint64_t b = b0 + u < B ? b0 + u : B - 1;  // clamped: the duplicate result is dropped
+            c[u] = C + b * stride;
+            acc[u].lo = 0; acc[u].hi = 0;
+        }
+        uint32_t last[DEC_U];
+#pragma unroll
+        for (int u = 0; u < DEC_U; u++) last[u] = lane == 0 ? c[u][n] : 0u;
+#pragma unroll 4
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint32_t wv = w[i];
+#pragma unroll
+            for (int u = 0; u < DEC_U; u++) acc_mad(acc[u], wv, c[u][i]);
+        }
+#pragma unroll
+        for (int u = 0; u < DEC_U; u++) {
+            uint32_t r = acc_finish(acc[u].lo, acc[u].hi, mod);
+            r = qf_addmod(r, qf_red_u64(last[u], mod), mod.q);
+            r = wave_sum_modq(r, mod.q);
+            if (lane == 0 && b0 + u < B) bits[b0 + u] = (uint8_t)qf_decide_bit(r, mod);
+        }
     }
 }
 int qf_launch_dot_decode(qf_ctx *ctx, const uint32_t *w, uint32_t n, const QfMod &mod, const uint32_t *C,
                          uint64_t B, uint8_t *bits) {
-    uint64_t blocks = (B + 3) / 4;
-    if (blocks > 256 * 64) blocks = 256 * 64;
+    uint64_t blocks = (B + 4 * DEC_U - 1) / (4 * DEC_U);  // 4 waves per block, DEC_U ciphertexts per wave
+    if (blocks > 256 * 32) blocks = 256 * 32;
     if (blocks == 0) return QF_OK;
     QfTimer t(ctx, &ctx->ms_decode);
     hipLaunchKernelGGL(qf_dot_decode_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, w, n, mod, C, B, bits);
