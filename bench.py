@@ -51,11 +51,26 @@ INT8_PEAK_TOPS = 5033.0   # 2048 int8 op/clk/SIMD x 1024 SIMDs x 2.4 GHz (MI355X
 HBM_PEAK_GBS = 8000.0
 
 
+def spin(fn, ms):
+    """Untimed: run fn back to back for about `ms` milliseconds of GPU time (DVFS settle)."""
+    if ms <= 0:
+        return
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--spin-ms", type=float, default=60.0,
+                    help="untimed: keep the GPU busy this long before the W warmup steps (the clock the chip "
+                         "holds under load settles ~20 ms after idle; measured steady state is 15 %% faster than "
+                         "the first launches)")
     ap.add_argument("--batch", type=int, default=65536, help="messages per GPU per step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-ring", action="store_true", help="skip the secondary ring-polymul measurement")
@@ -121,6 +136,7 @@ def main():
         ctx.matmul(key, xbits, X_BITS, B, msg=msg, out=cipher)
         ctx.dot_decode(w, q, cipher, out=bits)
 
+    spin(step, args.spin_ms)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -180,8 +196,7 @@ def main():
         a = ctx.sample_uniform(SEED, 6, rank * 2 * Br * nr, Br * nr, qr).view(Br, nr)
         b = ctx.sample_uniform(SEED, 6, (rank * 2 + 1) * Br * nr, Br * nr, qr).view(Br, nr)
         c = torch.empty_like(a)
-        for _ in range(2):
-            ring.polymul(a, b, out=c)
+        spin(lambda: ring.polymul(a, b, out=c), args.spin_ms)
         torch.cuda.synchronize()
         rs = max(3, args.steps // 2)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -239,7 +254,11 @@ def main():
         dist.destroy_process_group()
 
 
+SPIN_MS = 60.0
+
+
 def _time_loop(fn, steps, warmup, dist, world):
+    spin(fn, SPIN_MS)
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
@@ -360,6 +379,14 @@ def other_workloads(args):
             uu = ctx.sample_uniform(SEED, 6, lo * n, B * n, q).view(B, n)
             el, ms = _time_loop(lambda: ring.fdh_verify(a, sig, uu, 10 ** 12), args.steps, args.warmup, dist, world)
             bytes_per = (mbar + 1) * 4 * n
+            # the caller step in front of it: SHA-256 hash-to-R_q of B 32-byte messages on the device
+            msgs = [("message %08d of the FDH verification batch" % (lo + i)) for i in range(B)]
+            packed = ctx.pack_messages(msgs)
+            hout = ctx.empty_u32(B, n)
+            _, hms = _time_loop(lambda: ctx.hash_packed(packed, n, 1, q, out=hout), max(3, args.steps // 2), 1, dist, world)
+            out["hash_to_ring"] = {"metric": "SHA-256 hash-to-R_q on the device (n = 1024 digests of a 43-byte message each)",
+                                   "value": B / (hms * 1e-3), "unit": "messages/s", "launch_ms": hms,
+                                   "digests_per_s": B * n / (hms * 1e-3)}
             out.update({"metric": "GPV-ring FDH verifications/sec (k+2 = 32 ring products each)", "value": Btot * args.steps / el, "unit": "verifications/s"})
         gbs = B * bytes_per / (ms * 1e-3) / 1e9
         out.update({"scaling": "strong", "ms_per_step": el / args.steps * 1e3, "dtype": "u32 (exact Z_q, Shoup NTT)",
@@ -396,6 +423,7 @@ def other_workloads(args):
 
 if __name__ == "__main__":
     _a = parse()
+    SPIN_MS = _a.spin_ms
     if _a.workload == "regev":
         main()
     else:

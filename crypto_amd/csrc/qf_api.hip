@@ -165,6 +165,13 @@ static int key_build(qf_ctx *ctx, uint32_t *u32_dev_owned, uint32_t rows, uint32
     if (e != hipSuccess) { hipFree(k->u32); delete k; ctx->err = "hipMalloc(key planes) failed"; return QF_ERR_DEVICE; }
     int rc = qf_launch_recode(ctx, k->u32, QF_X_U32, (size_t)cols * 4, rows, cols, k->mod, k->la, k->ks, k->planes, ctx->flag);
     if (rc) { qf_key_destroy(k); return rc; }
+    const uint32_t r = rows % 32;
+    if (r && r * (uint32_t)k->la <= 32) {
+        if (hipMalloc((void **)&k->rem_planes, (size_t)k->ks * 1024) != hipSuccess) { qf_key_destroy(k); return qf_fail(ctx, QF_ERR_DEVICE, "hipMalloc(key remainder planes) failed"); }
+        k->rem_rows = r;
+        rc = qf_launch_recode_rem(ctx, k->u32, cols, rows - r, r, k->mod, k->la, k->ks, k->rem_planes);
+        if (rc) { qf_key_destroy(k); return rc; }
+    }
     uint32_t flag = 0;
     if (hipMemcpyAsync(&flag, ctx->flag, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess) { qf_key_destroy(k); return qf_fail(ctx, QF_ERR_DEVICE, "key recode failed"); }
@@ -216,6 +223,7 @@ void qf_key_destroy(qf_key *key) {
     hipSetDevice(key->device);
     hipDeviceSynchronize();
     if (key->planes) hipFree(key->planes);
+    if (key->rem_planes) hipFree(key->rem_planes);
     if (key->u32) hipFree(key->u32);
     delete key;
 }

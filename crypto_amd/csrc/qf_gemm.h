@@ -9,6 +9,8 @@ struct QfGemmArgs {
     uint32_t rows;           // key rows (= output row length)
     const uint8_t *xbits;    // BITS: bit-packed rows
     size_t xstride;          // BITS: row stride in bytes (multiple of 16)
+    const int8_t *rem_planes;// bit operands: packed remainder block of the key [ks][64][16], or null
+    uint32_t rem_rows;       //   its rows (rows mod 32)
     const int8_t *xplanes;   // PLANES: batch digit planes, fragment order [mb][ks][LB][64][16]
     uint64_t B;              // messages
     const uint32_t *addend;  // B x rows or null

@@ -88,6 +88,51 @@ __global__ __launch_bounds__(256) void qf_recode_kernel(const uint8_t *__restric
     if (bad) atomicOr(flag, 1u);
 }
 
+// packed remainder block of a key (see qf_gemm_body PACKED): one fragment per k-step whose row
+// i*L + l is digit l of trailing row `first_row + i`
+template <int L>
+__global__ __launch_bounds__(256) void qf_recode_rem_kernel(const uint32_t *__restrict__ src, uint32_t cols,
+                                                            uint32_t first_row, uint32_t rem_rows, QfMod mod,
+                                                            uint32_t ks_pad, int8_t *__restrict__ planes) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = gid & 63;
+    const uint64_t ksi = gid >> 6;
+    if (ksi >= ks_pad) return;
+    const uint32_t p = lane & 31, ir = p / L, l = p % L;
+    const uint32_t k0 = (uint32_t)ksi * 32 + 16 * (lane >> 5);
+    const int64_t maxpos = qf_maxpos(L);
+    uint32_t dig[4] = {0, 0, 0, 0};
+    if (ir < rem_rows) {
+        const uint32_t *rp = src + (size_t)(first_row + ir) * cols;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t k = k0 + j;
+            int64_t rep = 0;
+            if (k < cols) {
+                const uint32_t c = qf_red_u64(rp[k], mod);
+                rep = (int64_t)c <= maxpos ? (int64_t)c : (int64_t)c - (int64_t)mod.q;
+            }
+            int64_t d = 0;
+            for (uint32_t t = 0; t <= l; t++) { d = ((rep + 128) & 255) - 128; rep = (rep - d) >> 8; }
+            dig[j >> 2] |= (uint32_t)(d & 255) << (8 * (j & 3));
+        }
+    }
+    *(uint4 *)(planes + (ksi * 64 + lane) * 16) = make_uint4(dig[0], dig[1], dig[2], dig[3]);
+}
+int qf_launch_recode_rem(qf_ctx *ctx, const uint32_t *src, uint32_t cols, uint32_t first_row, uint32_t rem_rows,
+                         const QfMod &mod, int digits, uint32_t ks_pad, int8_t *planes) {
+    dim3 grid((unsigned)(((uint64_t)ks_pad * 64 + 255) / 256)), block(256);
+    switch (digits) {
+        case 1: hipLaunchKernelGGL(qf_recode_rem_kernel<1>, grid, block, 0, ctx->stream, src, cols, first_row, rem_rows, mod, ks_pad, planes); break;
+        case 2: hipLaunchKernelGGL(qf_recode_rem_kernel<2>, grid, block, 0, ctx->stream, src, cols, first_row, rem_rows, mod, ks_pad, planes); break;
+        case 3: hipLaunchKernelGGL(qf_recode_rem_kernel<3>, grid, block, 0, ctx->stream, src, cols, first_row, rem_rows, mod, ks_pad, planes); break;
+        case 4: hipLaunchKernelGGL(qf_recode_rem_kernel<4>, grid, block, 0, ctx->stream, src, cols, first_row, rem_rows, mod, ks_pad, planes); break;
+        default: return qf_fail(ctx, QF_ERR_ARG, "recode: digits must be 1..4");
+    }
+    QF_HIP(ctx, hipGetLastError());
+    return QF_OK;
+}
+
 int qf_digits_for_modulus(uint32_t q) {
     // smallest L with q <= 256^L: every residue then has a representative with L balanced digits
     int L = 1;
@@ -167,13 +212,23 @@ struct QfSched {
     }
 };
 
-template <int LA, int LB, int WN, int MW, bool BITS>
-__global__ __launch_bounds__(QF_NW * 64, (MW * WN * (LA + LB - 1) * 16 <= 48 ? 4 : 2)) void qf_gemm_kernel(QfGemmArgs a) {
+// PACKED (bit operands, LB = 1 only): the tile's last row block is the key's "remainder block" --
+// the r = rows mod 32 trailing rows, whose r*LA digit rows are packed into ONE fragment per k-step
+// (fragment row i*LA + l = digit l of trailing row i; a.rem_planes) instead of LA mostly-empty ones.
+// With LB = 1 every digit has its own accumulator anyway, so digits may sit in different fragment
+// rows; the epilogue gathers the LA partial sums of a row from neighbouring lanes.  Regev n = 256:
+// 257 rows cost 8*3 + 1 = 25 MFMAs per k-step and message block instead of 27.
+template <int LA, int LB, int WN, int MW, bool BITS, bool PACKED>
+__device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a) {
+    static_assert(!PACKED || (BITS && LB == 1 && MW == 1), "packed remainder block: bit operands only");
     constexpr int S = LA + LB - 1;
+    constexpr int NBF = PACKED ? (WN - 1) * LA + 1 : WN * LA;   // key fragments per k-step
+#define QF_LJ(j_) ((PACKED && (j_) == WN - 1) ? 1 : LA)         /* digits (fragments) of row block j */
+#define QF_FOFF(j_, ks_, l_) ((PACKED && (j_) == WN - 1) ? ((WN - 1) * QF_KS * LA + (ks_)) : (((j_) * QF_KS + (ks_)) * LA + (l_)))
     // prefetch operand fragments one k-step ahead when both register sets fit next to the
     // accumulators (2 waves/SIMD => 256 VGPRs per lane)
     constexpr bool PF = MW * WN * S * 16 + 8 * (WN * LA + MW * LB) <= 224;
-    constexpr int FRAGS = WN * QF_KS * LA;           // key fragments (1 KiB each) per k-tile
+    constexpr int FRAGS = NBF * QF_KS;               // key fragments (1 KiB each) per k-tile
     constexpr int TILE_BYTES = FRAGS * 1024;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 3 * TILE_BYTES
 
@@ -213,6 +268,8 @@ __global__ __launch_bounds__(QF_NW * 64, (MW * WN * (LA + LB - 1) * 16 <= 48 ? 4
         rbi_ = rbi_ < a.rb ? rbi_ : a.rb - 1; /* padded column tile: harmless duplicate */           \
         const int8_t *g_ = a.kplanes +                                                               \
             ((((size_t)rbi_ * a.ks + (size_t)(kt_)*QF_KS) * LA + rem_) * 64 + lane) * 16;            \
+        if (PACKED && f_ >= (WN - 1) * QF_KS * LA)                                                   \
+            g_ = a.rem_planes + (((size_t)(kt_)*QF_KS + (f_ - (WN - 1) * QF_KS * LA)) * 64 + lane) * 16; \
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g_,         \
             (__attribute__((address_space(3))) void *)(smem + (buf_)*TILE_BYTES + f_ * 1024),        \
             16, 0, 0);                                                                               \
@@ -269,13 +326,13 @@ __global__ __launch_bounds__(QF_NW * 64, (MW * WN * (LA + LB - 1) * 16 <= 48 ? 4
 #ifdef QF_ABL_NOLDS
 #define QF_LOAD_B(set_, tile_, ks_)                                                               \
     _Pragma("unroll") for (int j_ = 0; j_ < WN; j_++)                                             \
-        _Pragma("unroll") for (int l_ = 0; l_ < LA; l_++)                                         \
+        _Pragma("unroll") for (int l_ = 0; l_ < QF_LJ(j_); l_++)                                  \
             asm volatile("" : "+v"(bf[set_][j_ * LA + l_]));
 #else
 #define QF_LOAD_B(set_, tile_, ks_)                                                               \
     _Pragma("unroll") for (int j_ = 0; j_ < WN; j_++)                                             \
-        _Pragma("unroll") for (int l_ = 0; l_ < LA; l_++)                                         \
-            bf[set_][j_ * LA + l_] = *(const v4i *)((tile_) + ((j_ * QF_KS + (ks_)) * LA + l_) * 1024);
+        _Pragma("unroll") for (int l_ = 0; l_ < QF_LJ(j_); l_++)                                  \
+            bf[set_][j_ * LA + l_] = *(const v4i *)((tile_) + QF_FOFF(j_, ks_, l_) * 1024);
 #endif
 #define QF_LOAD_A(set_, atset_, kt_, ks_)                                                         \
     _Pragma("unroll") for (int m_ = 0; m_ < MW; m_++) {                                           \
@@ -290,7 +347,7 @@ __global__ __launch_bounds__(QF_NW * 64, (MW * WN * (LA + LB - 1) * 16 <= 48 ? 4
     } }
 #define QF_MFMAS(set_)                                                                            \
     _Pragma("unroll") for (int j_ = 0; j_ < WN; j_++)                                             \
-        _Pragma("unroll") for (int l_ = 0; l_ < LA; l_++)                                         \
+        _Pragma("unroll") for (int l_ = 0; l_ < QF_LJ(j_); l_++)                                  \
             _Pragma("unroll") for (int m_ = 0; m_ < MW; m_++)                                     \
                 _Pragma("unroll") for (int b_ = 0; b_ < LB; b_++)                                 \
                     acc[m_][j_][l_ + b_] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[set_][m_][b_], bf[set_][j_ * LA + l_], \
@@ -298,7 +355,7 @@ __global__ __launch_bounds__(QF_NW * 64, (MW * WN * (LA + LB - 1) * 16 <= 48 ? 4
     // pin the interleave: one prefetch LDS read between consecutive MFMA groups (hipcc otherwise
     // sinks every read to just before its use and waits lgkmcnt(0) in front of every MFMA)
 #define QF_INTERLEAVE()                                                                           \
-    _Pragma("unroll") for (int i_ = 0; i_ < WN * LA; i_++) {                                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < NBF; i_++) {                                          \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                        \
         __builtin_amdgcn_sched_group_barrier(0x008, MW * LB, 0);                                  \
     }                                                                                             \
@@ -307,7 +364,7 @@ __global__ __launch_bounds__(QF_NW * 64, (MW * WN * (LA + LB - 1) * 16 <= 48 ? 4
     // same, with NV_ LDS-DMA issues spread evenly between the MFMA groups: a DMA issue holds its wave
     // for ~60-180 cycles, and a burst of them right behind the barrier stalls both waves of a SIMD
     // at once; one at a time, the partner wave's MFMAs cover it
-#define QF_INTERLEAVE_V(NV_) QfSched<0, WN * LA, (NV_), MW * LB>::run(); __builtin_amdgcn_sched_barrier(0);
+#define QF_INTERLEAVE_V(NV_) QfSched<0, NBF, (NV_), MW * LB>::run(); __builtin_amdgcn_sched_barrier(0);
 
     QF_LOAD_AT(0, 0)
     QF_STAGE(0, 0)
@@ -395,6 +452,25 @@ __global__ __launch_bounds__(QF_NW * 64, (MW * WN * (LA + LB - 1) * 16 <= 48 ? 4
     for (int i = 0; i < MW; i++) {
 #pragma unroll
     for (int j = 0; j < WN; j++) {
+        if (PACKED && j == WN - 1) {
+            // remainder block: lane p = i*LA + l holds digit l of trailing row i; gather the LA partial
+            // sums of a row from the neighbouring lanes, the lane with l = 0 reduces and stores
+            const uint32_t p = lane & 31, ir = p / LA, l0 = p % LA;
+            const uint32_t krow = (rb0 + j) * 32 + ir;
+            const bool owner = l0 == 0 && ir < a.rem_rows;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const uint64_t mrow = (mb0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                int64_t x = 0;
+#pragma unroll
+                for (int l = 0; l < LA; l++)
+                    x += (int64_t)__shfl(acc[i][j][0][r], (int)(lane - l0 + l), 64) * (int64_t)a.cs[l];
+                if (!owner || mrow >= a.B) continue;
+                if (a.msg && krow == lastrow && (a.msg[mrow] & 1)) x += (int64_t)a.mod.qhalf;
+                a.out[mrow * a.rows + krow] = qf_red_i64(x, a.mod);
+            }
+            continue;
+        }
         const uint32_t krow = (rb0 + j) * 32 + (lane & 31);
         if (rb0 + j >= a.rb || krow >= a.rows) continue;
 #pragma unroll
@@ -424,6 +500,17 @@ __global__ __launch_bounds__(QF_NW * 64, (MW * WN * (LA + LB - 1) * 16 <= 48 ? 4
 #endif
 }
 
+template <int LA, int LB, int WN, int MW, bool BITS>
+__global__ __launch_bounds__(QF_NW * 64, (MW * WN * (LA + LB - 1) * 16 <= 48 ? 4 : 2)) void qf_gemm_kernel(QfGemmArgs a) {
+    qf_gemm_body<LA, LB, WN, MW, BITS, false>(a);
+}
+// bit operands on a key with a packed remainder block: the last column tile ends with it
+template <int LA, int WN>
+__global__ __launch_bounds__(QF_NW * 64, (WN * LA * 16 <= 48 ? 4 : 2)) void qf_gemm_packed_kernel(QfGemmArgs a) {
+    if (blockIdx.y + 1 == gridDim.y) qf_gemm_body<LA, 1, WN, 1, true, true>(a);
+    else qf_gemm_body<LA, 1, WN, 1, true, false>(a);
+}
+
 // widest column tile (in 32-row blocks) whose accumulators fit comfortably: WN*S*16 <= 192 regs
 static int qf_wn_max(int S) {
     int w = 12 / S;
@@ -448,6 +535,22 @@ static int qf_gemm_dispatch_wn(qf_ctx *ctx, const QfGemmArgs &args) {
     return QF_OK;
 }
 
+template <int LA, int WN>
+static int qf_gemm_dispatch_packed(qf_ctx *ctx, const QfGemmArgs &args) {
+    size_t lds = 3 * (size_t)WN * LA * QF_KS * 1024;
+    static bool attr_done = false;
+    if (!attr_done) {
+        QF_HIP(ctx, hipFuncSetAttribute((const void *)qf_gemm_packed_kernel<LA, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    uint64_t nmsgtiles = (args.B + 32 * QF_NW - 1) / (32 * QF_NW);
+    dim3 grid((unsigned)nmsgtiles, args.rb / WN), block(QF_NW * 64);   // rb = full blocks + 1, a multiple of WN here
+    QfTimer t(ctx, &ctx->ms_gemm);
+    hipLaunchKernelGGL((qf_gemm_packed_kernel<LA, WN>), grid, block, lds, ctx->stream, args);
+    QF_HIP(ctx, hipGetLastError());
+    return QF_OK;
+}
+
 // Wave tile = MW*32 messages x WN*32 key rows; its accumulators (16 registers per 32x32 block and
 // digit weight) must leave room for operand fragments inside the 256-VGPR budget of 2 waves/SIMD.
 template <int LA, int LB, bool BITS>
@@ -466,6 +569,24 @@ static int qf_gemm_dispatch(qf_ctx *ctx, const QfGemmArgs &args) {
         uint32_t tiles = (args.rb + w - 1) / w;
         double cost = (double)tiles * w * (1.0 + 0.3 / w);
         if (cost < best_cost) { best_cost = cost; best = w; }
+    }
+    if constexpr (BITS) {
+        // packed remainder block: needs the slots (full blocks + 1) to split evenly into tiles of w
+        if (args.rem_planes && !getenv("QF_GEMM_NOPACK")) {
+            int bw = 0;
+            double bc = best_cost;
+            for (int w = WMAX; w >= 1; w--) {
+                if (args.rb % w) continue;
+                double cost = ((double)args.rb * LA - (LA - 1)) / LA * (1.0 + 0.3 / w);
+                if (cost < bc) { bc = cost; bw = w; }
+            }
+            switch (bw) {
+                case 1: return qf_gemm_dispatch_packed<LA, 1>(ctx, args);
+                case 2: if constexpr (WMAX >= 2) return qf_gemm_dispatch_packed<LA, 2>(ctx, args); break;
+                case 3: if constexpr (WMAX >= 3) return qf_gemm_dispatch_packed<LA, 3>(ctx, args); break;
+                case 4: if constexpr (WMAX >= 4) return qf_gemm_dispatch_packed<LA, 4>(ctx, args); break;
+            }
+        }
     }
     int mw = 1;
     if (const char *e = getenv("QF_GEMM_WN")) {  // experiments only
@@ -492,6 +613,7 @@ int qf_launch_gemm(qf_ctx *ctx, const qf_key *key, const void *X, int x_is_bits,
     (void)qf_wn_max;
     QfGemmArgs a;
     a.kplanes = key->planes; a.rb = key->rb; a.ks = key->ks; a.rows = key->rows;
+    a.rem_planes = (x_is_bits && lb == 1) ? key->rem_planes : nullptr; a.rem_rows = key->rem_rows;
     a.xbits = x_is_bits ? (const uint8_t *)X : nullptr;
     a.xstride = x_stride;
     a.xplanes = x_is_bits ? nullptr : (const int8_t *)X;

@@ -30,6 +30,10 @@ struct qf_key {
     uint32_t ks = 0;    // k-steps of 32 (padded to a multiple of 4)
     int8_t *planes = nullptr;  // [rb][ks][la][64 lanes][16 B]   (MFMA fragment order)
     uint32_t *u32 = nullptr;   // rows x cols row-major copy
+    // packed remainder block (bit-operand products): when r = rows mod 32 satisfies 0 < r*la <= 32
+    // the r trailing rows' digits fill ONE fragment per k-step, [ks][64 lanes][16 B]
+    int8_t *rem_planes = nullptr;
+    uint32_t rem_rows = 0;
     QfMod mod;
 };
 
@@ -78,6 +82,8 @@ int qf_digits_for_modulus(uint32_t q);
 int qf_launch_recode(qf_ctx *ctx, const void *src, int kind, size_t stride_bytes, uint32_t rows,
                      uint32_t cols, const QfMod &mod, int digits, uint32_t ks_pad, int8_t *planes,
                      uint32_t *flag);
+int qf_launch_recode_rem(qf_ctx *ctx, const uint32_t *src, uint32_t cols, uint32_t first_row, uint32_t rem_rows,
+                         const QfMod &mod, int digits, uint32_t ks_pad, int8_t *planes);
 int qf_launch_gemm(qf_ctx *ctx, const qf_key *key, const void *X, int x_is_bits, size_t x_stride,
                    int lb, uint64_t B, const uint32_t *addend, const uint8_t *msg, uint32_t *out);
 int qf_launch_transpose_u32(qf_ctx *ctx, const uint32_t *src, uint32_t rows, uint32_t cols, uint32_t *dst);

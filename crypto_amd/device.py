@@ -152,22 +152,29 @@ class Context:
         _check(self.h, self.lib.qf_vecmat_modq_host(self.h, key.h, x.ctypes.data, y.ctypes.data))
         return y
 
+    def pack_messages(self, messages):
+        """UTF-8 bytes of all strings back to back + B+1 byte offsets, both on the device
+        (the operand layout of qf_hash_to_mat_zq_sha256_dev)."""
+        raw = [m.encode() if isinstance(m, str) else bytes(m) for m in messages]
+        offs = np.zeros(len(raw) + 1, np.uint64)
+        if raw:
+            offs[1:] = np.cumsum([len(r) for r in raw])
+        blob = np.frombuffer(b"".join(raw) or b"\0", np.uint8).copy()
+        return self.to_dev_u8(blob), torch.from_numpy(offs.view(np.int64)).to(self.device), len(raw)
+
+    def hash_packed(self, packed, rows: int, cols: int, q: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        d_blob, d_offs, B = packed
+        if out is None:
+            out = self.empty_u32(B, rows * cols)
+        if B:
+            _check(self.h, self.lib.qf_hash_to_mat_zq_sha256_dev(self.h, d_blob.data_ptr(), d_offs.data_ptr(), B, rows, cols, q,
+                                                                 out.data_ptr()))
+        return out
+
     def hash_to_mat_zq_sha256(self, messages, rows: int, cols: int, q: int) -> torch.Tensor:
         """hash/sha256.rs:110-133 for a list of strings at once: (B, rows*cols) residues on the device
         (rows = n, cols = 1: the ring target of HashMatPolynomialRingZq{1,1}, sha256.rs:249-256)."""
-        raw = [m.encode() if isinstance(m, str) else bytes(m) for m in messages]
-        B = len(raw)
-        out = self.empty_u32(B, rows * cols)
-        if B == 0:
-            return out
-        offs = np.zeros(B + 1, np.uint64)
-        offs[1:] = np.cumsum([len(r) for r in raw])
-        blob = np.frombuffer(b"".join(raw) or b"\0", np.uint8).copy()
-        d_blob = self.to_dev_u8(blob)
-        d_offs = torch.from_numpy(offs.view(np.int64)).to(self.device)
-        _check(self.h, self.lib.qf_hash_to_mat_zq_sha256_dev(self.h, d_blob.data_ptr(), d_offs.data_ptr(), B, rows, cols, q,
-                                                             out.data_ptr()))
-        return out
+        return self.hash_packed(self.pack_messages(messages), rows, cols, q)
 
     def dot_decode(self, w: torch.Tensor, q: int, Cm: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         B = Cm.shape[0]

@@ -33,7 +33,13 @@ def test_matvec_vecmat(ctx, rows, cols, q):
 
 
 @pytest.mark.parametrize("n,m,q,B", [(13, 154, 1427, 70), (50, 867, 124991, 300), (256, 6168, 16777213, 513),
-                                     (3, 16, 13, 5), (64, 1000, 2147483629, 40), (31, 129, 251, 33)])
+                                     (3, 16, 13, 5), (64, 1000, 2147483629, 40), (31, 129, 251, 33),
+                                     # packed remainder block (rows mod 32 = r, r*digits <= 32): r*LA = 32 exactly with
+                                     # LA = 2 and LA = 4, r*LA = 30 at LA = 3, tiles of 4 / 2 / 1 row blocks, a lone
+                                     # packed block, and r*LA = 33 which must NOT pack
+                                     (47, 300, 40009, 70), (39, 200, 2147483629, 33), (41, 500, 8380417, 257),
+                                     (100, 640, 8380417, 300), (229, 256, 12289, 64), (7, 99, 1000003, 19),
+                                     (42, 130, 8380417, 65)])
 def test_matmul_bits_regev_shape(ctx, n, m, q, B):
     """Regev::enc batched (regev.rs:396-414): pk*x + message in the last entry."""
     pk = co.sample_uniform(SEED, 1, 0, (n + 1) * m, q).reshape(n + 1, m)
@@ -174,3 +180,47 @@ def test_hash_to_mat_zq_sha256_vs_oracle(ctx, rows, cols, q):
     for b, m in enumerate(msgs):
         ref = np.array(po.hash_to_mat_zq(m, rows, cols, q), dtype=np.uint64).reshape(-1)
         assert np.array_equal(got[b].astype(np.uint64), ref), (b, m[:10])
+
+
+def test_c_abi_error_codes_and_empty_batches(ctx):
+    """Raw C ABI: the codes a binding turns back into the reference's panics (include/qfgpu.h),
+    and empty batches, which launch nothing and succeed."""
+    import ctypes as C
+    from crypto_amd import _lib
+    lib, h = ctx.lib, ctx.h
+    q, n = 1073479681, 1024
+    ring = ctx.ring(n, q)
+    rk = ring.key(co.sample_uniform(SEED, 1, 0, n, q)[None])           # one polynomial
+    u = ctx.to_dev_u32(np.zeros((2, n), np.uint32))
+    mu = ctx.to_dev_u8(np.zeros((2, n // 8), np.uint8))
+    # RingLPR::enc needs pk = (a, b): a key with one polynomial is a dimension error
+    rc = lib.qf_ringlpr_enc_dev(h, ring.h, rk.h, u.data_ptr(), u.data_ptr(), u.data_ptr(), mu.data_ptr(), 2, u.data_ptr(), u.data_ptr())
+    assert rc == _lib.QF_ERR_DIM
+    # a ring key of another ring: modulus mismatch
+    ring2 = ctx.ring(n, 12289)
+    rc = lib.qf_ringlpr_dec_dev(h, ring2.h, rk.h, u.data_ptr(), u.data_ptr(), 2, mu.data_ptr())
+    assert rc == _lib.QF_ERR_MODULUS
+    # null operands
+    assert lib.qf_polymul_dev(h, ring.h, None, u.data_ptr(), 2, u.data_ptr()) == _lib.QF_ERR_ARG
+    assert lib.qf_dot_decode_dev(h, None, 4, 17, u.data_ptr(), 1, mu.data_ptr()) == _lib.QF_ERR_ARG
+    # empty batches
+    assert lib.qf_polymul_dev(h, ring.h, None, None, 0, None) == 0
+    assert lib.qf_dot_decode_dev(h, None, 4, 17, None, 0, None) == 0
+    assert lib.qf_fdh_ring_verify_dev(h, ring.h, rk.h, None, None, 0, 0, None, None) == 0
+    assert lib.qf_hash_to_mat_zq_sha256_dev(h, None, None, 0, n, 1, q, None) == 0
+    # bad ring degrees / moduli
+    hr = C.c_void_p()
+    assert lib.qf_ring_create(h, 1000, q, C.byref(hr)) == _lib.QF_ERR_NOTSUP       # not a power of two
+    assert lib.qf_ring_create(h, 1024, 2 ** 31, C.byref(hr)) == _lib.QF_ERR_MODULUS
+    assert lib.qf_hash_to_mat_zq_sha256_dev(h, u.data_ptr(), u.data_ptr(), 1, 0, 1, q, u.data_ptr()) == _lib.QF_ERR_DIM
+    assert b"" != lib.qf_last_error(h)
+
+
+def test_dot_decode_ragged_and_large_n(ctx):
+    """Batch sizes around the 4-ciphertexts-per-wave grouping and n that is not a multiple of 64."""
+    for n, q, B in [(50, 124991, 1), (50, 124991, 5), (257, 16777213, 4099), (1000, 1073741789, 7), (3, 7, 130)]:
+        s = co.sample_uniform(SEED, 2, 0, n, q)
+        Cm = co.sample_uniform(SEED, 9, 0, B * (n + 1), q).reshape(B, n + 1)
+        w = ((q - s.astype(np.int64)) % q).astype(np.uint32)
+        bits = ctx.to_host_u8(ctx.dot_decode(ctx.to_dev_u32(w), q, ctx.to_dev_u32(Cm)))
+        assert np.array_equal(bits, co.dot_decode_batch(s, q, Cm)), (n, q, B)
