@@ -75,7 +75,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-ring", action="store_true", help="skip the secondary ring-polymul measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--workload", default="regev", choices=["regev", "sis", "lpr", "ringlpr", "fdh", "matvec"],
+    ap.add_argument("--workload", default="regev", choices=["regev", "sis", "lpr", "ringlpr", "fdh", "matvec", "regev_cycle"],
                     help="regev = the headline (BASELINE config 2); the others are the remaining configs, "
                          "each printing its own JSON line")
     return ap.parse_args()
@@ -393,6 +393,36 @@ def other_workloads(args):
                     "config": {"workload": f"{wl} n=1024 (BASELINE config 5)", "n": n, "q": q, "global_batch": Btot},
                     "roofline": {"kernel": "qf_ring_wave_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "launch_ms": ms}})
+    elif wl == "regev_cycle":
+        # BASELINE config 1 = the reference's own criterion bench (benches/regev.rs:15-57): one
+        # gen + enc + dec cycle of ONE bit at new_from_n(n), n = 50 and the sweep 10..60.  The CPU
+        # port of the reference's call structure beside the same cycle through the GPU host layer
+        # (single-message path: kernel (c) + decode, key upload included -- as the reference
+        # regenerates the key inside its timed loop).  A CPU reference point, no roofline.
+        from oracle import coracle as co
+        from crypto_amd.construction.pk_encryption import Regev
+        rows = []
+        for nn in (10, 20, 30, 40, 50, 60):
+            r = Regev.new_from_n(nn, ctx=ctx)
+            W = r.noise_width
+            reps = 20
+            t1 = time.perf_counter()
+            for i in range(reps):
+                assert co.regev_cycle(r.n, r.m, r.q, W, SEED + i, 1) == 1
+            cpu_ms = (time.perf_counter() - t1) / reps * 1e3
+            pk, sk = r.gen(); r.dec(sk, r.enc(pk, 1))
+            t1 = time.perf_counter()
+            for i in range(reps):
+                pk, sk = r.gen()
+                assert r.dec(sk, r.enc(pk, 1)) == 1
+            gpu_ms = (time.perf_counter() - t1) / reps * 1e3
+            rows.append({"n": r.n, "m": r.m, "q": r.q, "cpu_port_ms_per_cycle": cpu_ms, "gpu_host_layer_ms_per_cycle": gpu_ms})
+        n50 = [x for x in rows if x["n"] == 50][0]
+        out.update({"metric": "Regev gen+enc+dec cycles/sec, one bit, n=50 (benches/regev.rs default)", "value": 1e3 / n50["cpu_port_ms_per_cycle"],
+                    "unit": "cycles/s (CPU port of the reference's call structure, 1 core)", "scaling": "weak", "ms_per_step": n50["cpu_port_ms_per_cycle"],
+                    "dtype": "u32/u128 (exact Z_q)", "config": {"workload": "Regev single-bit cycle sweep n=10..60 (BASELINE config 1)"},
+                    "sweep": rows, "roofline": None,
+                    "note": "single-message calls are launch/PCIe-latency bound on a GPU; the GPU is for the batched forms (configs 2-5)"})
     elif wl == "matvec":
         # single-message SIS hash, matrix cache-cold: rotate over > 256 MiB of distinct keys
         n, q = 512, 8380417

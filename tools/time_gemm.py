@@ -6,8 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from crypto_amd.device import Context, X_BITS, X_U32
 ctx = Context(0)
 
-def timeit(fn, reps=10):
-    for _ in range(3):
+def timeit(fn, reps=60):
+    for _ in range(40):   # settle the clock the chip holds under load
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
