@@ -11,7 +11,9 @@ struct QfGemmArgs {
     size_t xstride;          // BITS: row stride in bytes (multiple of 16)
     const int8_t *rem_planes;// bit operands: packed remainder block of the key [ks][64][16], or null
     uint32_t rem_rows;       //   its rows (rows mod 32)
-    const int8_t *xplanes;   // PLANES: batch digit planes, fragment order [mb][ks][LB][64][16]
+    const int8_t *xplanes;   // PLANES: batch digit planes, fragment order [mb][ks][xlb_total][64][16]
+    uint32_t xlb_total;      //   digits stored per (message block, k-step)
+    uint32_t xlb_off;        //   first digit this launch consumes (its LB digits are xlb_off .. xlb_off+LB-1)
     uint64_t B;              // messages
     const uint32_t *addend;  // B x rows or null
     const uint8_t *msg;      // B or null

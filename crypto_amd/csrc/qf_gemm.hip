@@ -285,7 +285,7 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a) {
         const uint64_t mrow_c = mrow_l < a.B ? mrow_l : (a.B - 1);        // clamped for loads
         xrow[i] = BITS ? a.xbits + mrow_c * a.xstride : nullptr;
         const uint64_t mb_c = mb0 + i < nmb ? mb0 + i : nmb - 1;
-        xfrag[i] = BITS ? nullptr : a.xplanes + (mb_c * a.ks * LB) * 1024 + (size_t)lane * 16;
+        xfrag[i] = BITS ? nullptr : a.xplanes + ((mb_c * a.ks * a.xlb_total) + a.xlb_off) * 1024 + (size_t)lane * 16;
     }
 
     // ---- main loop.  Three LDS buffers: the DMA of k-tile t+2 is issued in the middle of tile t
@@ -315,7 +315,7 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a) {
     } else if (ATILE) {                                                                           \
         _Pragma("unroll") for (int i_ = 0; i_ < NAT; i_++)                                        \
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(at[set_][m_][i_])               \
-                         : "v"(xfrag[m_] + ((size_t)(kt_)*QF_KS * LB + i_) * 1024) : "memory");   \
+                         : "v"(xfrag[m_] + (((size_t)(kt_)*QF_KS + i_ / LB) * a.xlb_total + i_ % LB) * 1024) : "memory"); \
     } }
 #define QF_WAIT_AT(set_, n_)                                                                      \
     if (BITS || ATILE) {                                                                          \
@@ -343,7 +343,7 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a) {
         _Pragma("unroll") for (int b_ = 0; b_ < LB; b_++) af[set_][m_][b_] = at[atset_][m_][(ks_)*LB + b_]; \
     } else {                                                                                      \
         _Pragma("unroll") for (int b_ = 0; b_ < LB; b_++)                                         \
-            af[set_][m_][b_] = *(const v4i *)(xfrag[m_] + (((size_t)(kt_)*QF_KS + (ks_)) * LB + b_) * 1024); \
+            af[set_][m_][b_] = *(const v4i *)(xfrag[m_] + (((size_t)(kt_)*QF_KS + (ks_)) * a.xlb_total + b_) * 1024); \
     } }
 #define QF_MFMAS(set_)                                                                            \
     _Pragma("unroll") for (int j_ = 0; j_ < WN; j_++)                                             \
@@ -635,12 +635,44 @@ int qf_launch_gemm(qf_ctx *ctx, const qf_key *key, const void *X, int x_is_bits,
         if (ab >= 2147483648.0L) return qf_fail(ctx, QF_ERR_NOTSUP, "gemm: K too large for int32 accumulation");
     }
     const int la = key->la;
+    a.xlb_total = (uint32_t)lb; a.xlb_off = 0;
+    if (x_is_bits && lb != 1) return qf_fail(ctx, QF_ERR_ARG, "gemm: bit operand has one digit");
+    // Wide batch operands (LB digits) on a long inner dimension: one pass PER DIGIT of the operand
+    // with the single-digit kernel -- pass b multiplies by 2^(8b) through shifted recombination
+    // constants and adds the previous passes' output as its addend.  Same MFMA count as the fused
+    // <LA,LB> kernel, but S = LA accumulators per row block instead of LA+LB-1 and 4 instead of
+    // 4*LB operand fragments in registers, so the wider tile and the register-prefetch pipeline
+    // fit: +10 % on SIS with Z_q inputs (K = 11,776).  Each pass re-reads and re-writes the output,
+    // so short inner dimensions (LPR, K = 1,024: 0.90 -> 1.29 ms) stay on the fused kernel.
+    // QF_GEMM_MULTIPASS=0/1 forces either.
+    bool multipass = (uint64_t)key->ks * 32 >= 4096;
+    if (const char *e = getenv("QF_GEMM_MULTIPASS")) multipass = atoi(e) != 0;
+    if (!x_is_bits && lb > 1 && multipass) {
+        QfGemmArgs p = a;
+        float ms_total = 0.f;
+        for (int b = 0; b < lb; b++) {
+            p.xlb_off = (uint32_t)b;
+            for (int s = 0; s < 8; s++) p.cs[s] = s + b < 8 ? a.cs[s + b] : 0;
+            p.addend = b == 0 ? addend : out;   // in place: every thread reads the element it then writes
+            p.msg = b == 0 ? msg : nullptr;
+            int rc = QF_ERR_NOTSUP;
+            switch (la) {
+                case 1: rc = qf_gemm_dispatch<1, 1, false>(ctx, p); break;
+                case 2: rc = qf_gemm_dispatch<2, 1, false>(ctx, p); break;
+                case 3: rc = qf_gemm_dispatch<3, 1, false>(ctx, p); break;
+                case 4: rc = qf_gemm_dispatch<4, 1, false>(ctx, p); break;
+            }
+            if (rc) return rc;
+            ms_total += ctx->ms_gemm;
+        }
+        if (ctx->timing) ctx->ms_gemm = ms_total;   // "gemm" time of the call = all passes
+        return QF_OK;
+    }
 #define QF_CASE(LA_, LB_)                                                            \
     if (la == LA_ && lb == LB_) {                                                    \
         return x_is_bits ? qf_gemm_dispatch<LA_, 1, true>(ctx, a)                    \
                          : qf_gemm_dispatch<LA_, LB_, false>(ctx, a);                \
     }
-    if (x_is_bits && lb != 1) return qf_fail(ctx, QF_ERR_ARG, "gemm: bit operand has one digit");
     QF_CASE(1, 1) QF_CASE(2, 1) QF_CASE(3, 1) QF_CASE(4, 1)
     QF_CASE(2, 2) QF_CASE(3, 2) QF_CASE(4, 2)
     QF_CASE(3, 3) QF_CASE(4, 3)

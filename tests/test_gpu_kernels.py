@@ -224,3 +224,19 @@ def test_dot_decode_ragged_and_large_n(ctx):
         w = ((q - s.astype(np.int64)) % q).astype(np.uint32)
         bits = ctx.to_host_u8(ctx.dot_decode(ctx.to_dev_u32(w), q, ctx.to_dev_u32(Cm)))
         assert np.array_equal(bits, co.dot_decode_batch(s, q, Cm)), (n, q, B)
+
+
+def test_matmul_multipass_long_inner_dimension(ctx):
+    """Wide operands on K >= 4096 take the one-pass-per-digit path (qf_launch_gemm): same bits as
+    the oracle, with addend and message, for 2- and 3-digit operands."""
+    n, m, q, B = 40, 4500, 8380417, 50
+    A = co.sample_uniform(SEED, 1, 0, n * m, q).reshape(n, m)
+    key = ctx.key_upload(A, q)
+    v = co.sample_uniform(SEED, 6, 0, B * m, q).reshape(B, m)
+    e = co.sample_uniform(SEED, 4, 0, B * n, q).reshape(B, n)
+    msg = (co.sample_uniform(SEED, 5, 0, B, 2)).astype(np.uint8)
+    out = ctx.matmul(key, ctx.to_dev_u32(v), X_U32, B, addend=ctx.to_dev_u32(e), msg=ctx.to_dev_u8(msg))
+    assert np.array_equal(ctx.to_host_u32(out), co.matmul_batch(A, q, v, co.X_U32, B, addend=e, msg=msg))
+    r = co.sample_noise(SEED, 3, 0, B * m, q, 2000).reshape(B, m)
+    out = ctx.matmul(key, ctx.to_dev_u32(r), X_U32, B, x_digits=2)
+    assert np.array_equal(ctx.to_host_u32(out), co.matmul_batch(A, q, r, co.X_U32, B))

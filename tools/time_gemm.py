@@ -62,7 +62,7 @@ if "lpr" in which:
     ctx.set_timing(True)
     def run():
         ctx.matmul(key, r, X_U32, B, addend=e, x_digits=2, out=out)
-    for wn, mw in [(0, 0), (2, 1), (1, 1), (1, 2)]:
+    for wn, mw in [(0, 0), (2, 1), (3, 1), (4, 1)]:
         if wn:
             os.environ["QF_GEMM_WN"] = str(wn); os.environ["QF_GEMM_MW"] = str(mw)
         run(); run()
