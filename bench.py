@@ -178,9 +178,9 @@ def main():
         "config": {"workload": "Regev enc+dec round trip (BASELINE config 2)", "n": n, "m": m, "q": q,
                    "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"batch-shard x{world}",
                    "key_broadcast_ms": t_bcast * 1e3},
-        "roofline": {"kernel": "qf_gemm_kernel<3,1,3,1,bits>", "bound": "mfma", "achieved": achieved_tops,
+        "roofline": {"kernel": "qf_gemm_packed_kernel<3,3> (bit operands, packed remainder row block)", "bound": "mfma", "achieved": achieved_tops,
                      "peak": INT8_PEAK_TOPS, "unit": "TFLOP/s", "frac": achieved_tops / INT8_PEAK_TOPS,
-                     "traffic": pmc_traffic("qf_gemm_kernel") if B == 65536 else None, "launch_ms": gemm_ms,
+                     "traffic": pmc_traffic("qf_gemm_") if B == 65536 else None, "launch_ms": gemm_ms,
                      "note": "int8 multiply-accumulates counted as 2 ops; algorithmic ops = 2*La*Lb*(n+1)*m per encryption; "
                              "traffic = HBM bytes per launch from the committed PMC passes (profiles/r1/traffic.json); "
                              "sustained bare-MFMA rate on this data (tools/ubench_mfma): 3.4-3.65 POP/s at the 1.7-1.8 GHz the chip holds"},
