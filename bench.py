@@ -173,7 +173,7 @@ def main():
     out = {
         "metric": "encryptions/sec", "value": value, "unit": "encryptions/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int8 digits, i32/i64 accumulate (exact Z_q)",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int8", "dtype_note": "signed radix-2^8 digits on int8 MFMA, exact i32/i64 accumulation, canonical Z_q results",
         "data": "synthetic (seeded SplitMix64 on device)",
         "config": {"workload": "Regev enc+dec round trip (BASELINE config 2)", "n": n, "m": m, "q": q,
                    "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"batch-shard x{world}",

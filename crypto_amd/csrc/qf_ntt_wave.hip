@@ -248,41 +248,63 @@ __global__ __launch_bounds__(WV_THREADS) void qf_ring_wave_kernel(QfRingArgs a) 
                 dst[lane + 64 * r] = make_uint2(v, (uint32_t)((((uint64_t)v) << 32) / q));
             }
         } else if constexpr (MODE == MODE_RLPR_ENC) {
-            uint32_t xr[R], t[R];
+            // the noise polynomials are fetched ahead of the transforms that precede their use
+            // (e1 before the forward transform, e2 before the first inverse), so their HBM latency
+            // hides behind the butterflies instead of stalling the three resident waves
+            uint32_t xr[R], t[R], e1[R], e2[R];
+            const uint32_t *n1 = a.in1 + item * N, *n2 = a.in2 + item * N;
+#pragma unroll
+            for (int r = 0; r < R; r++) e1[r] = n1[lane + 64 * r];
             load_nat(xr, a.in0 + item * N);
-            W::forward(xr, lane, buf, twf, twg_f, q);
             // message bits: word j of the row holds coefficients 32j..32j+31
             const uint32_t *mrow = (const uint32_t *)(a.mu + item * (uint64_t)(N / 8));
             const uint32_t mword = mrow[lane < (uint32_t)(N / 32) ? lane : 0];
-#pragma unroll 1
-            for (int which = 0; which < 2; which++) {
-                const uint2 *kh = (const uint2 *)a.key + (size_t)which * N;
+            W::forward(xr, lane, buf, twf, twg_f, q);
+            const uint2 *kha = (const uint2 *)a.key, *khb = (const uint2 *)a.key + N;
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    uint2 k2 = kh[lane + 64 * r];
-                    uint32_t v = xr[r] * k2.x - __umulhi(xr[r], k2.y) * q;  // [0,2q)
-                    t[r] = LAZY ? v : min(v, v - q);
-                }
-                W::inverse(t, lane, buf, twi, twg_i, q);
-                const uint32_t *noise = (which ? a.in2 : a.in1) + item * N;
-                uint32_t *dst = (which ? a.out1 : a.out0) + item * N;
+            for (int r = 0; r < R; r++) {
+                uint2 k2 = kha[lane + 64 * r];
+                uint32_t v = xr[r] * k2.x - __umulhi(xr[r], k2.y) * q;  // [0,2q)
+                t[r] = LAZY ? v : min(v, v - q);
+            }
+            constexpr bool PRE2 = R <= 16;  // n = 2048: 128 data registers would spill
+            if (PRE2) {
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    uint32_t val = finish(t[r]);
-                    uint32_t e = wv_red32<true>(noise[lane + 64 * r], one_p, q);
-                    val += e; val = min(val, val - q);
-                    if (which) {
-                        uint32_t wlo = __builtin_amdgcn_readlane(mword, (2 * r) % (N / 32));
-                        uint32_t whi = __builtin_amdgcn_readlane(mword, (2 * r + 1) % (N / 32));
-                        uint32_t wsel = lane < 32 ? wlo : whi;
-                        uint32_t add = ((wsel >> (lane & 31)) & 1u) ? a.mod.qhalf : 0u;
-                        val += add; val = min(val, val - q);
-                    }
-                    dst[lane + 64 * r] = val;
-                }
+                for (int r = 0; r < R; r++) e2[r] = n2[lane + 64 * r];
+            }
+            W::inverse(t, lane, buf, twi, twg_i, q);
+            uint32_t *du = a.out0 + item * N, *dv = a.out1 + item * N;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                uint32_t val = finish(t[r]) + wv_red32<true>(e1[r], one_p, q);
+                du[lane + 64 * r] = min(val, val - q);
+            }
+            if (!PRE2) {
+#pragma unroll
+                for (int r = 0; r < R; r++) e2[r] = n2[lane + 64 * r];
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                uint2 k2 = khb[lane + 64 * r];
+                uint32_t v = xr[r] * k2.x - __umulhi(xr[r], k2.y) * q;
+                t[r] = LAZY ? v : min(v, v - q);
+            }
+            W::inverse(t, lane, buf, twi, twg_i, q);
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                uint32_t val = finish(t[r]) + wv_red32<true>(e2[r], one_p, q);
+                val = min(val, val - q);
+                uint32_t wlo = __builtin_amdgcn_readlane(mword, (2 * r) % (N / 32));
+                uint32_t whi = __builtin_amdgcn_readlane(mword, (2 * r + 1) % (N / 32));
+                uint32_t wsel = lane < 32 ? wlo : whi;
+                val += ((wsel >> (lane & 31)) & 1u) ? a.mod.qhalf : 0u;
+                dv[lane + 64 * r] = min(val, val - q);
             }
         } else if constexpr (MODE == MODE_RLPR_DEC) {
-            uint32_t x[R];
+            uint32_t x[R], vraw[R];
+            const uint32_t *vv = a.in1 + item * N;
+#pragma unroll
+            for (int r = 0; r < R; r++) vraw[r] = vv[lane + 64 * r];  // fetched ahead of the transforms
             load_nat(x, a.in0 + item * N);
             W::forward(x, lane, buf, twf, twg_f, q);
             const uint2 *kh = (const uint2 *)a.key;
@@ -293,12 +315,11 @@ __global__ __launch_bounds__(WV_THREADS) void qf_ring_wave_kernel(QfRingArgs a) 
                 x[r] = LAZY ? v : min(v, v - q);
             }
             W::inverse(x, lane, buf, twi, twg_i, q);
-            const uint32_t *vv = a.in1 + item * N;
             uint32_t myword = 0;
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 uint32_t su = finish(x[r]);
-                uint32_t w = qf_submod(wv_red32<true>(vv[lane + 64 * r], one_p, q), su, q);
+                uint32_t w = qf_submod(wv_red32<true>(vraw[r], one_p, q), su, q);
                 bool bit = qf_ring_dist(w, a.mod.qhalf, q) < qf_ring_dist(w, 0, q);
                 uint64_t m = __ballot(bit);  // coefficients 64r .. 64r+63
                 if (lane == (uint32_t)(2 * r)) myword = (uint32_t)m;
