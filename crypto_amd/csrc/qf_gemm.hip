@@ -511,12 +511,6 @@ __global__ __launch_bounds__(QF_NW * 64, (WN * LA * 16 <= 48 ? 4 : 2)) void qf_g
     else qf_gemm_body<LA, 1, WN, 1, true, false>(a);
 }
 
-// widest column tile (in 32-row blocks) whose accumulators fit comfortably: WN*S*16 <= 192 regs
-static int qf_wn_max(int S) {
-    int w = 12 / S;
-    return w < 1 ? 1 : (w > 4 ? 4 : w);
-}
-
 template <int LA, int LB, int WN, int MW, bool BITS>
 static int qf_gemm_dispatch_wn(qf_ctx *ctx, const QfGemmArgs &args) {
     constexpr int FRAGS = WN * QF_KS * LA;
@@ -610,7 +604,6 @@ static int qf_gemm_dispatch(qf_ctx *ctx, const QfGemmArgs &args) {
 
 int qf_launch_gemm(qf_ctx *ctx, const qf_key *key, const void *X, int x_is_bits, size_t x_stride,
                    int lb, uint64_t B, const uint32_t *addend, const uint8_t *msg, uint32_t *out) {
-    (void)qf_wn_max;
     QfGemmArgs a;
     a.kplanes = key->planes; a.rb = key->rb; a.ks = key->ks; a.rows = key->rows;
     a.rem_planes = (x_is_bits && lb == 1) ? key->rem_planes : nullptr; a.rem_rows = key->rem_rows;
