@@ -50,11 +50,11 @@ __device__ __forceinline__ void sha_compress(uint32_t (&st)[8], uint32_t (&w)[16
 }
 
 // decimal digits of v into p[0..], returns the count
-__device__ __forceinline__ uint32_t put_dec(uint8_t *p, uint64_t v) {
-    uint8_t tmp[20];
-    uint32_t n = 0;
-    do { tmp[n++] = (uint8_t)('0' + v % 10); v /= 10; } while (v);
-    for (uint32_t i = 0; i < n; i++) p[i] = tmp[n - 1 - i];
+__device__ __forceinline__ uint32_t put_dec(uint8_t *p, uint32_t v) {
+    // 32-bit only: the division by 10 is a multiply-high, and the digit count comes from compares
+    const uint32_t n = 1 + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) +
+                       (v >= 1000000u) + (v >= 10000000u) + (v >= 100000000u) + (v >= 1000000000u);
+    for (uint32_t i = n; i-- > 0;) { const uint32_t d = v / 10u; p[i] = (uint8_t)('0' + (v - d * 10u)); v = d; }
     return n;
 }
 
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(SH_THREADS) void qf_hash_to_zq_kernel(const uint8_t
                                                                    const uint64_t *__restrict__ offs, uint64_t B,
                                                                    uint32_t rows, uint32_t cols, QfMod mod,
                                                                    uint32_t *__restrict__ out) {
-    __shared__ uint8_t pre_all[SH_THREADS * SH_PRE];
+    __shared__ __attribute__((aligned(16))) uint8_t pre_all[SH_THREADS * SH_PRE];
     uint8_t *pre = pre_all + threadIdx.x * SH_PRE;
     const uint64_t E = (uint64_t)rows * cols;
     const uint64_t idx = (uint64_t)blockIdx.x * SH_THREADS + threadIdx.x;
@@ -91,10 +91,29 @@ __global__ __launch_bounds__(SH_THREADS) void qf_hash_to_zq_kernel(const uint8_t
     for (uint64_t blk = 0; blk < nblk; blk++) {
         uint32_t w[16];
         const uint64_t base = blk * 64;
+        if (base >= pl && base + 64 <= total) {
+            // block entirely inside the message: no per-byte case analysis
+            const uint8_t *mp = m + (base - pl);
 #pragma unroll
-        for (int t = 0; t < 16; t++) {
-            const uint64_t p = base + 4 * t;
-            w[t] = (byte_at(p) << 24) | (byte_at(p + 1) << 16) | (byte_at(p + 2) << 8) | byte_at(p + 3);
+            for (int t = 0; t < 16; t++)
+                w[t] = ((uint32_t)mp[4 * t] << 24) | ((uint32_t)mp[4 * t + 1] << 16) | ((uint32_t)mp[4 * t + 2] << 8) | mp[4 * t + 3];
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const uint64_t p = base + 4 * t;
+                uint32_t wv;
+                if (p + 4 <= pl) {                        // inside the prefix: one aligned LDS word
+                    wv = __builtin_bswap32(*(const uint32_t *)(pre + p));
+                } else if (p >= pl && p + 4 <= total) {   // inside the message
+                    const uint8_t *mp = m + (p - pl);
+                    wv = ((uint32_t)mp[0] << 24) | ((uint32_t)mp[1] << 16) | ((uint32_t)mp[2] << 8) | mp[3];
+                } else if (p > total) {                   // pure padding
+                    wv = 0;
+                } else {                                  // a word that straddles a boundary
+                    wv = (byte_at(p) << 24) | (byte_at(p + 1) << 16) | (byte_at(p + 2) << 8) | byte_at(p + 3);
+                }
+                w[t] = wv;
+            }
         }
         if (blk == nblk - 1) { w[14] = (uint32_t)(bitlen >> 32); w[15] = (uint32_t)bitlen; }
         sha_compress(st, w);
