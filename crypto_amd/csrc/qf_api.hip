@@ -455,6 +455,7 @@ int qf_ringlpr_enc_dev(qf_ctx *ctx, const qf_ring *ring, const qf_rkey *pk, cons
     if (!r_dev || !e1_dev || !e2_dev || !mu_bits_dev || !u_dev || !v_dev) return qf_fail(ctx, QF_ERR_ARG, "ringlpr enc: null operand");
     int rc = ring_match(ctx, ring, pk, 2);
     if (rc) return rc;
+    if (ring->wave && ((uintptr_t)mu_bits_dev & 3)) return qf_fail(ctx, QF_ERR_ARG, "ringlpr enc: mu_bits must be 4-byte aligned");
     QF_BIND(ctx);
     return qf_launch_ringlpr_enc(ctx, ring, pk, r_dev, e1_dev, e2_dev, mu_bits_dev, B, u_dev, v_dev);
 }
@@ -465,6 +466,7 @@ int qf_ringlpr_dec_dev(qf_ctx *ctx, const qf_ring *ring, const qf_rkey *sk, cons
     if (!u_dev || !v_dev || !mu_bits_dev) return qf_fail(ctx, QF_ERR_ARG, "ringlpr dec: null operand");
     int rc = ring_match(ctx, ring, sk, 1);
     if (rc) return rc;
+    if (ring->wave && ((uintptr_t)mu_bits_dev & 3)) return qf_fail(ctx, QF_ERR_ARG, "ringlpr dec: mu_bits must be 4-byte aligned");
     QF_BIND(ctx);
     return qf_launch_ringlpr_dec(ctx, ring, sk, u_dev, v_dev, B, mu_bits_dev);
 }

@@ -58,6 +58,20 @@ __global__ __launch_bounds__(256) void qf_recode_kernel(const uint8_t *__restric
     bool bad = false;
     if (row < rows) {
         const uint8_t *rp = src + (size_t)row * stride_bytes;
+        // the lane's 16 consecutive entries (64 bytes): four 16-byte loads when the run is aligned
+        // and inside the row, single words otherwise
+        uint32_t raw[16];
+        if (k0 + 16 <= cols && ((((uintptr_t)rp) + (size_t)k0 * 4) & 15) == 0) {
+            const uint4 *vp = (const uint4 *)(rp + (size_t)k0 * 4);
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const uint4 x = vp[v];
+                raw[4 * v] = x.x; raw[4 * v + 1] = x.y; raw[4 * v + 2] = x.z; raw[4 * v + 3] = x.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; j++) raw[j] = k0 + j < cols ? ((const uint32_t *)rp)[k0 + j] : 0u;
+        }
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             uint32_t k = k0 + j;
@@ -65,9 +79,9 @@ __global__ __launch_bounds__(256) void qf_recode_kernel(const uint8_t *__restric
             if (k < cols) {
                 uint32_t c;
                 if (kind == QF_X_U32) {
-                    c = qf_red_u64(((const uint32_t *)rp)[k], mod);
+                    c = qf_red_u64(raw[j], mod);
                 } else {
-                    int64_t v = ((const int32_t *)rp)[k];
+                    int64_t v = (int32_t)raw[j];
                     c = qf_red_i64(v, mod);
                 }
                 rep = (int64_t)c <= maxpos ? (int64_t)c : (int64_t)c - (int64_t)mod.q;

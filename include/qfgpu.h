@@ -146,7 +146,8 @@ int qf_polymul_dev(qf_ctx *ctx, const qf_ring *ring, const uint32_t *a_dev, cons
 /* RingLPR::enc for B messages (ring_lpr.rs:422-461), pk = rkey polys {0:a, 1:b}:
  *   u_i = a*r_i + e1_i ; v_i = b*r_i + e2_i + mu_i(X)*floor(q/2)
  * mu_bits_dev: B rows of ceil(n/8) bytes, bit k of row i = coefficient k of mu_i, i.e. the
- * bits of |message| mod 2^n (ring_lpr.rs:424-427,318-329). */
+ * bits of |message| mod 2^n (ring_lpr.rs:424-427,318-329).  mu_bits_dev must be 4-byte aligned
+ * (here and in qf_ringlpr_dec_dev); all polynomial operands are arrays of uint32_t. */
 int qf_ringlpr_enc_dev(qf_ctx *ctx, const qf_ring *ring, const qf_rkey *pk, const uint32_t *r_dev,
                        const uint32_t *e1_dev, const uint32_t *e2_dev, const uint8_t *mu_bits_dev,
                        uint64_t B, uint32_t *u_dev, uint32_t *v_dev);
