@@ -296,6 +296,16 @@ def other_workloads(args):
     from crypto_amd import sharding
     ctx = Context(local)
     wl = args.workload
+
+    def replicated(count, q_, shape):
+        """A public key / SIS matrix: generated on rank 0, replicated with ONE RCCL broadcast."""
+        t = ctx.empty_u32(*shape)
+        if rank == 0:
+            ctx.sample_uniform(SEED, 1, 0, count, q_, out=t.view(-1))
+        if world > 1:
+            dist.broadcast(t, src=0)
+        return t
+
     out = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
            "vs_baseline": None, "data": "synthetic (seeded SplitMix64 on device)"}
     if wl == "sis":
@@ -304,7 +314,7 @@ def other_workloads(args):
         Btot = 1 << 20
         lo, hi = sharding.shard_range(Btot, rank, world)
         B = hi - lo
-        A = ctx.sample_uniform(SEED, 1, 0, n * m, q).view(n, m)   # same seeded key on every rank == a broadcast key
+        A = replicated(n * m, q, (n, m))
         key = ctx.key_upload(A, q)
         xb = ctx.sample_bits(SEED, 3, lo, B, m)
         dig = ctx.empty_u32(B, n)
@@ -338,7 +348,7 @@ def other_workloads(args):
         Btot = 1 << 18
         lo, hi = sharding.shard_range(Btot, rank, world)
         B = hi - lo
-        pk = ctx.sample_uniform(SEED, 1, 0, (n + 1) * n, q).view(n + 1, n)
+        pk = replicated((n + 1) * n, q, (n + 1, n))
         key = ctx.key_upload(pk, q)
         r = ctx.sample_noise(SEED, 3, lo * n, B * n, q, W).view(B, n)
         e = ctx.sample_noise(SEED, 4, lo * (n + 1), B * (n + 1), q, W).view(B, n + 1)
@@ -367,7 +377,7 @@ def other_workloads(args):
             Btot = 1 << 18
             lo, hi = sharding.shard_range(Btot, rank, world)
             B = hi - lo
-            keys = ctx.sample_uniform(SEED, 1, 0, 2 * n, q).view(2, n)
+            keys = replicated(2 * n, q, (2, n))
             pk = ring.key(keys)
             r = ctx.sample_noise(SEED, 3, lo * n, B * n, q, W).view(B, n)
             e1 = ctx.sample_noise(SEED, 4, lo * n, B * n, q, W).view(B, n)
@@ -382,7 +392,7 @@ def other_workloads(args):
             Btot = 1 << 15
             lo, hi = sharding.shard_range(Btot, rank, world)
             B = hi - lo
-            a = ring.key(ctx.sample_uniform(SEED, 1, 0, mbar * n, q).view(mbar, n))
+            a = ring.key(replicated(mbar * n, q, (mbar, n)))
             sig = (ctx.sample_uniform(SEED, 7, lo * mbar * n, B * mbar * n, 201) - 100).view(B, mbar, n)
             uu = ctx.sample_uniform(SEED, 6, lo * n, B * n, q).view(B, n)
             el, ms = _time_loop(lambda: ring.fdh_verify(a, sig, uu, 10 ** 12), args.steps, args.warmup, dist, world)
