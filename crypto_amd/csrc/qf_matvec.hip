@@ -165,7 +165,7 @@ int qf_launch_vecmat(qf_ctx *ctx, const qf_key *key, const uint32_t *x, uint32_t
 // together), lanes stride over the n entries.  Each lane folds its split 64-bit sums to a canonical
 // residue once; the wave sum is then taken mod q with DPP adds inside each row of 16 lanes (no LDS
 // traffic) and four scalar reads.
-#define DEC_U 4
+#define DEC_U 8
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_addmod(uint32_t v, uint32_t q) {
     uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
