@@ -33,6 +33,14 @@ reference_kats = {
         "a": [[1], [2, 8, 8, 12], [11, 10, 7, 13], [9, 6, 6, 12], [6, 11, 1, 6], [3, 10, 2, 9]],
         "r": [[-1, 7, 6, -8], [0, -2, 4], [0, 3, -4, 1], [6, 4, -1, 3]],
         "e": [[-4, 8, -3, 7], [1, -2, 2, 4], [-6, 7, -5], [-7, 10, -12, -15]]},
+    # sample/g_trapdoor/short_basis_classical.rs:281-303 (fixed trapdoor, n=2, q=8) with the is_trapdoor
+    # identity of gadget_classical.rs:300-322 / g_trapdoor.rs:168-184:  A * [R ; I] = G = I_2 (x) (1,2,4)  mod 8
+    "classical_trapdoor_n2_q8": {
+        "q": 8,
+        "A": [[2, 6, 2, 5, 3, 0, 1, 1, 1, 6, 5, 0, 6], [6, 0, 3, 1, 5, 6, 2, 7, 0, 3, 7, 7, 0]],
+        "R": [[0, 1, 0, 1, 1, 0], [-1, 1, 0, 0, 0, -1], [-1, 0, -1, -1, -1, 0], [-1, 1, 0, 0, 0, 1],
+              [-1, -1, 0, 1, 0, 1], [-1, 0, 0, -1, 0, 1], [0, -1, 0, 0, 0, 0]],
+        "G": [[1, 2, 4, 0, 0, 0], [0, 0, 0, 1, 2, 4]]},
     "sha256": {"Hello World!": "7f83b1657ff1fc53b92dc18148a1d65dfc2d4b1fa3d677284addd200126d9069",
                "qfall": "eb6ed1369a670050bd04b24036e8c29144b0f6b10166dc9c8b4987a6026c715f"},
     "hash_to_zq": [["Hello World!", 7, 2], ["Hello World!", 256, 150], ["qfall", 16, 12]],

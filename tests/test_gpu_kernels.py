@@ -240,3 +240,17 @@ def test_matmul_multipass_long_inner_dimension(ctx):
     r = co.sample_noise(SEED, 3, 0, B * m, q, 2000).reshape(B, m)
     out = ctx.matmul(key, ctx.to_dev_u32(r), X_U32, B, x_digits=2)
     assert np.array_equal(ctx.to_host_u32(out), co.matmul_batch(A, q, r, co.X_U32, B))
+
+
+def test_fixed_classical_trapdoor_kat_on_device(ctx):
+    """The reference's fixed trapdoor (short_basis_classical.rs:281-303): A*[R;I] = G mod 8 through
+    kernel (a) (signed operand, one column per batch item) and kernel (c)."""
+    import json, os
+    k = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))["classical_trapdoor_n2_q8"]
+    q, A, G = k["q"], np.array(k["A"], np.uint32), np.array(k["G"], np.uint32)
+    T = np.vstack([np.array(k["R"], np.int64), np.eye(6, dtype=np.int64)])
+    key = ctx.key_upload(A, q)
+    out = ctx.matmul(key, ctx.to_dev_i32(np.ascontiguousarray(T.T)), X_I32, 6)
+    assert np.array_equal(ctx.to_host_u32(out), G.T)
+    for j in range(6):
+        assert ctx.matvec(key, (T[:, j] % q).astype(np.uint32)).tolist() == G[:, j].tolist()

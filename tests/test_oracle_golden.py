@@ -171,3 +171,20 @@ def test_multithreaded_variants_agree():
     assert np.array_equal(c1, co.matmul_batch(pk, q, xb, co.X_BITS, B, mt=True))
     s = co.sample_uniform(SEED, 2, 0, n, q)
     assert np.array_equal(co.dot_decode_batch(s, q, c1), co.dot_decode_batch(s, q, c1, mt=True))
+
+
+def test_fixed_classical_trapdoor_kat():
+    """short_basis_classical.rs:281-303 with the is_trapdoor identity (gadget_classical.rs:300-322):
+    A * [R ; I] = I_2 (x) (1,2,4) mod 8 -- a known answer for the Z_q matrix product (the arithmetic
+    of kernels a/c) from the reference's own fixed test data."""
+    k = KATS["classical_trapdoor_n2_q8"]
+    q = k["q"]
+    A = np.array(k["A"], np.uint32)
+    T = np.vstack([np.array(k["R"], np.int64), np.eye(6, dtype=np.int64)])          # 13 x 6
+    G = np.array(k["G"], np.uint32)
+    for j in range(6):
+        col = (T[:, j] % q).astype(np.uint32)
+        assert co.matvec(A, col, q).tolist() == G[:, j].tolist()
+        assert po.matvec(A.tolist(), col.tolist(), q) == G[:, j].tolist()
+    cols = np.ascontiguousarray(T.T).astype(np.int32)                               # 6 "messages" of 13 entries
+    assert np.array_equal(co.matmul_batch(A, q, cols, co.X_I32, 6), G.T)
