@@ -254,3 +254,28 @@ def test_fixed_classical_trapdoor_kat_on_device(ctx):
     assert np.array_equal(ctx.to_host_u32(out), G.T)
     for j in range(6):
         assert ctx.matvec(key, (T[:, j] % q).astype(np.uint32)).tolist() == G[:, j].tolist()
+
+
+def test_fixed_ring_trapdoor_kat_on_device(ctx):
+    """The reference's fixed ring trapdoor (short_basis_ring.rs:357-378, gadget_ring.rs:71-77) in
+    Z_16[X]/(X^4+1): a_{2+i} = 2^i - (a_bar*r_i + e_i) through the product kernel, and
+    a*[e_i; r_i; I_i] = g_i (is_trapdoor, gadget_ring.rs:189-210) through the fused FDH kernel."""
+    import json, os
+    k = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))["ring_trapdoor_n4_q16"]
+    n, q = k["n"], k["q"]
+    pad = lambda p: list(p) + [0] * (n - len(p))
+    a = np.array([pad(p) for p in k["a"]], np.uint32)
+    r = np.array([pad(p) for p in k["r"]], np.int64)
+    e = np.array([pad(p) for p in k["e"]], np.int64)
+    ring = ctx.ring(n, q)
+    abar = np.repeat(a[1:2], 4, axis=0)
+    ar = ctx.to_host_u32(ring.polymul(ctx.to_dev_u32(abar), ctx.to_dev_u32((r % q).astype(np.uint32)))).astype(np.int64)
+    g = np.zeros((4, n), np.int64); g[:, 0] = [1, 2, 4, 8]
+    assert np.array_equal((g - ar - e) % q, a[2:].astype(np.int64))
+    sigma = np.zeros((4, 6, n), np.int32)
+    sigma[:, 0], sigma[:, 1] = e, r
+    for i in range(4):
+        sigma[i, 2 + i, 0] = 1
+    ok, t = ring.fdh_verify(ring.key(a), ctx.to_dev_i32(sigma), ctx.to_dev_u32(g.astype(np.uint32)), 10 ** 6, want_t=True)
+    assert np.array_equal(ctx.to_host_u32(t).astype(np.int64), g % q)
+    assert ctx.to_host_u8(ok).tolist() == [1, 1, 1, 1]
