@@ -224,6 +224,7 @@ void qf_key_destroy(qf_key *key) {
     hipDeviceSynchronize();
     if (key->planes) hipFree(key->planes);
     if (key->rem_planes) hipFree(key->rem_planes);
+    for (int8_t *f : key->fold_planes) if (f) hipFree(f);
     if (key->u32) hipFree(key->u32);
     delete key;
 }

@@ -14,6 +14,7 @@ struct QfGemmArgs {
     const int8_t *xplanes;   // PLANES: batch digit planes, fragment order [mb][ks][xlb_total][64][16]
     uint32_t xlb_total;      //   digits stored per (message block, k-step)
     uint32_t xlb_off;        //   first digit this launch consumes (its LB digits are xlb_off .. xlb_off+LB-1)
+    uint32_t mchunk;         // PLANES: message tiles per raster chunk (0 = plain grid order), see qf_gemm_body
     uint64_t B;              // messages
     const uint32_t *addend;  // B x rows or null
     const uint8_t *msg;      // B or null

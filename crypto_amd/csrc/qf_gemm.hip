@@ -41,7 +41,8 @@ __global__ __launch_bounds__(256) void qf_recode_kernel(const uint8_t *__restric
                                                         size_t stride_bytes, uint32_t rows,
                                                         uint32_t cols, QfMod mod, uint32_t rb,
                                                         uint32_t ks_pad, int8_t *__restrict__ planes,
-                                                        uint32_t *__restrict__ flag) {
+                                                        uint32_t *__restrict__ flag, uint32_t mult,
+                                                        uint32_t fold, uint32_t fold_b) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = gid & 63;
     const uint64_t frag = gid >> 6;  // (rbi, ksi)
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(256) void qf_recode_kernel(const uint8_t *__restric
                     int64_t v = (int32_t)raw[j];
                     c = qf_red_i64(v, mod);
                 }
+                if (mult != 1) c = qf_red_u64((uint64_t)c * mult, mod);   // folded key planes: 256^b * A mod q
                 rep = (int64_t)c <= maxpos ? (int64_t)c : (int64_t)c - (int64_t)mod.q;
             }
 #pragma unroll
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void qf_recode_kernel(const uint8_t *__restric
             bad |= rep != 0;
         }
     }
-    int8_t *dst = planes + ((frag * L) * 64 + lane) * 16;
+    int8_t *dst = planes + (((frag * fold + fold_b) * L) * 64 + lane) * 16;
 #pragma unroll
     for (int l = 0; l < L; l++)
         *(uint4 *)(dst + (size_t)l * 1024) = make_uint4(dig[l][0], dig[l][1], dig[l][2], dig[l][3]);
@@ -157,16 +159,16 @@ int qf_digits_for_modulus(uint32_t q) {
 
 int qf_launch_recode(qf_ctx *ctx, const void *src, int kind, size_t stride_bytes, uint32_t rows,
                      uint32_t cols, const QfMod &mod, int digits, uint32_t ks_pad, int8_t *planes,
-                     uint32_t *flag) {
+                     uint32_t *flag, uint32_t mult, uint32_t fold, uint32_t fold_b) {
     uint32_t rb = (rows + 31) / 32;
     uint64_t threads = (uint64_t)rb * ks_pad * 64;
     dim3 grid((unsigned)((threads + 255) / 256)), block(256);
     const uint8_t *s = (const uint8_t *)src;
     switch (digits) {
-        case 1: hipLaunchKernelGGL(qf_recode_kernel<1>, grid, block, 0, ctx->stream, s, kind, stride_bytes, rows, cols, mod, rb, ks_pad, planes, flag); break;
-        case 2: hipLaunchKernelGGL(qf_recode_kernel<2>, grid, block, 0, ctx->stream, s, kind, stride_bytes, rows, cols, mod, rb, ks_pad, planes, flag); break;
-        case 3: hipLaunchKernelGGL(qf_recode_kernel<3>, grid, block, 0, ctx->stream, s, kind, stride_bytes, rows, cols, mod, rb, ks_pad, planes, flag); break;
-        case 4: hipLaunchKernelGGL(qf_recode_kernel<4>, grid, block, 0, ctx->stream, s, kind, stride_bytes, rows, cols, mod, rb, ks_pad, planes, flag); break;
+        case 1: hipLaunchKernelGGL(qf_recode_kernel<1>, grid, block, 0, ctx->stream, s, kind, stride_bytes, rows, cols, mod, rb, ks_pad, planes, flag, mult, fold, fold_b); break;
+        case 2: hipLaunchKernelGGL(qf_recode_kernel<2>, grid, block, 0, ctx->stream, s, kind, stride_bytes, rows, cols, mod, rb, ks_pad, planes, flag, mult, fold, fold_b); break;
+        case 3: hipLaunchKernelGGL(qf_recode_kernel<3>, grid, block, 0, ctx->stream, s, kind, stride_bytes, rows, cols, mod, rb, ks_pad, planes, flag, mult, fold, fold_b); break;
+        case 4: hipLaunchKernelGGL(qf_recode_kernel<4>, grid, block, 0, ctx->stream, s, kind, stride_bytes, rows, cols, mod, rb, ks_pad, planes, flag, mult, fold, fold_b); break;
         default: return qf_fail(ctx, QF_ERR_ARG, "recode: digits must be 1..4");
     }
     QF_HIP(ctx, hipGetLastError());
@@ -233,7 +235,7 @@ struct QfSched {
 // rows; the epilogue gathers the LA partial sums of a row from neighbouring lanes.  Regev n = 256:
 // 257 rows cost 8*3 + 1 = 25 MFMAs per k-step and message block instead of 27.
 template <int LA, int LB, int WN, int MW, bool BITS, bool PACKED>
-__device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a) {
+__device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a, const uint32_t bx, const uint32_t by) {
     static_assert(!PACKED || (BITS && LB == 1 && MW == 1), "packed remainder block: bit operands only");
     constexpr int S = LA + LB - 1;
     constexpr int NBF = PACKED ? (WN - 1) * LA + 1 : WN * LA;   // key fragments per k-step
@@ -250,8 +252,8 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
-    const uint32_t rb0 = blockIdx.y * WN;
-    const uint64_t mb0 = ((uint64_t)blockIdx.x * QF_NW + wave) * MW;  // this wave's first message block
+    const uint32_t rb0 = by * WN;
+    const uint64_t mb0 = ((uint64_t)bx * QF_NW + wave) * MW;  // this wave's first message block
     const uint32_t ntiles = a.ks / QF_KS;
 
     v16i acc[MW][WN][S];
@@ -514,15 +516,47 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a) {
 #endif
 }
 
+// Raster order.  Plain: workgroups run message-tile-fastest, so one column tile's key planes stay
+// in L2 while the whole batch streams by -- and the batch operand is re-read from HBM once per
+// column tile.  With a.mchunk set, CHUNKS of a.mchunk message tiles run through every column tile
+// before the next chunk starts: a chunk's operand tiles are re-used while still in L2 (workgroup
+// ids go round-robin over the 8 XCDs, so with a chunk that is a multiple of 8 a message tile
+// meets all its column tiles on the same XCD).  LPR n=1024 (537 MB of digit planes x 11 column
+// tiles): 3.31 -> 2.82 ms.
+__device__ __forceinline__ void qf_gemm_raster(const QfGemmArgs &a, uint32_t &bx, uint32_t &by) {
+    bx = blockIdx.x; by = blockIdx.y;
+    if (a.mchunk) {
+        const uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const uint32_t per = a.mchunk * gridDim.y;
+        const uint32_t base = (lin / per) * a.mchunk, w = lin % per;
+        const uint32_t sz = min(a.mchunk, gridDim.x - base);
+        by = w / sz; bx = base + w % sz;
+    }
+}
+
 template <int LA, int LB, int WN, int MW, bool BITS>
 __global__ __launch_bounds__(QF_NW * 64, (MW * WN * (LA + LB - 1) * 16 <= 48 ? 4 : 2)) void qf_gemm_kernel(QfGemmArgs a) {
-    qf_gemm_body<LA, LB, WN, MW, BITS, false>(a);
+    uint32_t bx, by;
+    qf_gemm_raster(a, bx, by);
+    qf_gemm_body<LA, LB, WN, MW, BITS, false>(a, bx, by);
 }
 // bit operands on a key with a packed remainder block: the last column tile ends with it
 template <int LA, int WN>
 __global__ __launch_bounds__(QF_NW * 64, (WN * LA * 16 <= 48 ? 4 : 2)) void qf_gemm_packed_kernel(QfGemmArgs a) {
-    if (blockIdx.y + 1 == gridDim.y) qf_gemm_body<LA, 1, WN, 1, true, true>(a);
-    else qf_gemm_body<LA, 1, WN, 1, true, false>(a);
+    uint32_t bx, by;
+    qf_gemm_raster(a, bx, by);
+    if (by + 1 == gridDim.y) qf_gemm_body<LA, 1, WN, 1, true, true>(a, bx, by);
+    else qf_gemm_body<LA, 1, WN, 1, true, false>(a, bx, by);
+}
+
+// message tiles per raster chunk (see qf_gemm_raster); QF_GEMM_MCHUNK / QF_GEMM_MCHUNK_BITS override
+static uint32_t qf_gemm_mchunk(bool bits, uint64_t nmsgtiles, unsigned coltiles) {
+    // digit planes: always (LPR 3.31 -> 2.82 ms, SIS with Z_q inputs 4.35 -> 3.98 ms); bit operands
+    // only on batches too large for the Infinity Cache (SIS B = 2^20: +2 %; Regev B = 65,536: -1 %)
+    uint64_t chunk = bits ? (nmsgtiles >= 1024 ? 32 : 0) : 32;
+    if (const char *e = getenv(bits ? "QF_GEMM_MCHUNK_BITS" : "QF_GEMM_MCHUNK")) chunk = (uint64_t)atoll(e);
+    if (coltiles > 1 && chunk && chunk < nmsgtiles && nmsgtiles * coltiles < 0x7fffffffull) return (uint32_t)chunk;
+    return 0;
 }
 
 template <int LA, int LB, int WN, int MW, bool BITS>
@@ -537,8 +571,10 @@ static int qf_gemm_dispatch_wn(qf_ctx *ctx, const QfGemmArgs &args) {
     }
     uint64_t nmsgtiles = (args.B + 32 * QF_NW * MW - 1) / (32 * QF_NW * MW);
     dim3 grid((unsigned)nmsgtiles, (args.rb + WN - 1) / WN), block(QF_NW * 64);
+    QfGemmArgs la = args;
+    la.mchunk = qf_gemm_mchunk(BITS, nmsgtiles, grid.y);
     QfTimer t(ctx, &ctx->ms_gemm);
-    hipLaunchKernelGGL((qf_gemm_kernel<LA, LB, WN, MW, BITS>), grid, block, lds, ctx->stream, args);
+    hipLaunchKernelGGL((qf_gemm_kernel<LA, LB, WN, MW, BITS>), grid, block, lds, ctx->stream, la);
     QF_HIP(ctx, hipGetLastError());
     return QF_OK;
 }
@@ -553,8 +589,10 @@ static int qf_gemm_dispatch_packed(qf_ctx *ctx, const QfGemmArgs &args) {
     }
     uint64_t nmsgtiles = (args.B + 32 * QF_NW - 1) / (32 * QF_NW);
     dim3 grid((unsigned)nmsgtiles, args.rb / WN), block(QF_NW * 64);   // rb = full blocks + 1, a multiple of WN here
+    QfGemmArgs la = args;
+    la.mchunk = qf_gemm_mchunk(true, nmsgtiles, grid.y);
     QfTimer t(ctx, &ctx->ms_gemm);
-    hipLaunchKernelGGL((qf_gemm_packed_kernel<LA, WN>), grid, block, lds, ctx->stream, args);
+    hipLaunchKernelGGL((qf_gemm_packed_kernel<LA, WN>), grid, block, lds, ctx->stream, la);
     QF_HIP(ctx, hipGetLastError());
     return QF_OK;
 }
@@ -616,6 +654,24 @@ static int qf_gemm_dispatch(qf_ctx *ctx, const QfGemmArgs &args) {
     return qf_fail(ctx, QF_ERR_NOTSUP, "gemm: no tile configuration");
 }
 
+// builds key->fold_planes[lb] on first use (see qf_key)
+static int qf_key_fold(qf_ctx *ctx, const qf_key *key, int lb) {
+    if (lb < 2 || lb > 4) return qf_fail(ctx, QF_ERR_ARG, "fold: operand digits must be 2..4");
+    if (key->fold_planes[lb]) return QF_OK;
+    int8_t *planes = nullptr;
+    size_t bytes = (size_t)key->rb * key->ks * lb * key->la * 1024;
+    if (hipMalloc((void **)&planes, bytes) != hipSuccess) return qf_fail(ctx, QF_ERR_DEVICE, "hipMalloc(folded key planes) failed");
+    uint64_t mult = 1 % key->q;
+    for (int b = 0; b < lb; b++) {
+        int rc = qf_launch_recode(ctx, key->u32, QF_X_U32, (size_t)key->cols * 4, key->rows, key->cols, key->mod, key->la,
+                                  key->ks, planes, ctx->flag, (uint32_t)mult, (uint32_t)lb, (uint32_t)b);
+        if (rc) { hipFree(planes); return rc; }
+        mult = (mult * 256) % key->q;
+    }
+    key->fold_planes[lb] = planes;
+    return QF_OK;
+}
+
 int qf_launch_gemm(qf_ctx *ctx, const qf_key *key, const void *X, int x_is_bits, size_t x_stride,
                    int lb, uint64_t B, const uint32_t *addend, const uint8_t *msg, uint32_t *out) {
     QfGemmArgs a;
@@ -624,6 +680,7 @@ int qf_launch_gemm(qf_ctx *ctx, const qf_key *key, const void *X, int x_is_bits,
     a.xbits = x_is_bits ? (const uint8_t *)X : nullptr;
     a.xstride = x_stride;
     a.xplanes = x_is_bits ? nullptr : (const int8_t *)X;
+    a.mchunk = 0;
     a.B = B; a.addend = addend; a.msg = msg; a.out = out; a.mod = key->mod; a.dbg = g_qf_dbg;
     // centred 2^(8s) mod q
     uint64_t p = 1 % key->q;
@@ -652,6 +709,28 @@ int qf_launch_gemm(qf_ctx *ctx, const qf_key *key, const void *X, int x_is_bits,
     // fit: +10 % on SIS with Z_q inputs (K = 11,776).  Each pass re-reads and re-writes the output,
     // so short inner dimensions (LPR, K = 1,024: 0.90 -> 1.29 ms) stay on the fused kernel.
     // QF_GEMM_MULTIPASS=0/1 forces either.
+    // Operand digits folded into the inner dimension (default): A*x = [A | 256A | ...]*[x_0; x_1; ...]
+    // over LB*K columns with the single-digit kernel.  Same MFMA count as the fused <LA,LB> kernel,
+    // S = LA accumulators per row block, ONE pass (no output re-read), the batch planes are consumed
+    // exactly as the recode kernel lays them out ([mb][ks][lb] = k-step ks*LB + b).  Needs
+    // LB*K*2^14 < 2^31 for the int32 accumulators.  QF_GEMM_FOLD=0 disables it.
+    bool fold = !x_is_bits && lb > 1 && (long double)lb * key->ks * 32.0L * 16384.0L < 2147483648.0L;
+    if (const char *e = getenv("QF_GEMM_FOLD")) fold = fold && atoi(e) != 0;
+    if (fold) {
+        int rc = qf_key_fold(ctx, key, lb);
+        if (rc) return rc;
+        QfGemmArgs p = a;
+        p.kplanes = key->fold_planes[lb];
+        p.ks = key->ks * (uint32_t)lb;
+        p.xlb_total = 1; p.xlb_off = 0;
+        switch (la) {
+            case 1: return qf_gemm_dispatch<1, 1, false>(ctx, p);
+            case 2: return qf_gemm_dispatch<2, 1, false>(ctx, p);
+            case 3: return qf_gemm_dispatch<3, 1, false>(ctx, p);
+            case 4: return qf_gemm_dispatch<4, 1, false>(ctx, p);
+        }
+        return qf_fail(ctx, QF_ERR_NOTSUP, "gemm: digit count not instantiated");
+    }
     bool multipass = (uint64_t)key->ks * 32 >= 4096;
     if (const char *e = getenv("QF_GEMM_MULTIPASS")) multipass = atoi(e) != 0;
     if (!x_is_bits && lb > 1 && multipass) {

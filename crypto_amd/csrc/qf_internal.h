@@ -34,6 +34,10 @@ struct qf_key {
     // the r trailing rows' digits fill ONE fragment per k-step, [ks][64 lanes][16 B]
     int8_t *rem_planes = nullptr;
     uint32_t rem_rows = 0;
+    // folded planes for an LB-digit batch operand (built on first use): k-step ks*LB + b holds the
+    // digits of 256^b * A mod q, so A*x = [A | 256A | ...] * [x_0 ; x_1 ; ...] runs as ONE
+    // single-digit product over LB*K columns.  [rb][ks*LB][la][64 lanes][16 B]
+    mutable int8_t *fold_planes[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     QfMod mod;
 };
 
@@ -81,7 +85,7 @@ int qf_ws2_reserve(qf_ctx *ctx, size_t bytes);
 int qf_digits_for_modulus(uint32_t q);
 int qf_launch_recode(qf_ctx *ctx, const void *src, int kind, size_t stride_bytes, uint32_t rows,
                      uint32_t cols, const QfMod &mod, int digits, uint32_t ks_pad, int8_t *planes,
-                     uint32_t *flag);
+                     uint32_t *flag, uint32_t mult = 1, uint32_t fold = 1, uint32_t fold_b = 0);
 int qf_launch_recode_rem(qf_ctx *ctx, const uint32_t *src, uint32_t cols, uint32_t first_row, uint32_t rem_rows,
                          const QfMod &mod, int digits, uint32_t ks_pad, int8_t *planes);
 int qf_launch_gemm(qf_ctx *ctx, const qf_key *key, const void *X, int x_is_bits, size_t x_stride,
