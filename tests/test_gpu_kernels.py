@@ -226,9 +226,13 @@ def test_dot_decode_ragged_and_large_n(ctx):
         assert np.array_equal(bits, co.dot_decode_batch(s, q, Cm)), (n, q, B)
 
 
-def test_matmul_multipass_long_inner_dimension(ctx):
-    """Wide operands on K >= 4096 take the one-pass-per-digit path (qf_launch_gemm): same bits as
+@pytest.mark.parametrize("env", [{}, {"QF_GEMM_FOLD": "0"}, {"QF_GEMM_FOLD": "0", "QF_GEMM_MULTIPASS": "0"}])
+def test_matmul_wide_operand_paths(ctx, monkeypatch, env):
+    """Wide operands, the three ways qf_launch_gemm can run them -- digits folded into the inner
+    dimension (default), one pass per digit (K >= 4096), the fused <LA,LB> kernel: same bits as
     the oracle, with addend and message, for 2- and 3-digit operands."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     n, m, q, B = 40, 4500, 8380417, 50
     A = co.sample_uniform(SEED, 1, 0, n * m, q).reshape(n, m)
     key = ctx.key_upload(A, q)
@@ -279,3 +283,25 @@ def test_fixed_ring_trapdoor_kat_on_device(ctx):
     ok, t = ring.fdh_verify(ring.key(a), ctx.to_dev_i32(sigma), ctx.to_dev_u32(g.astype(np.uint32)), 10 ** 6, want_t=True)
     assert np.array_equal(ctx.to_host_u32(t).astype(np.int64), g % q)
     assert ctx.to_host_u8(ok).tolist() == [1, 1, 1, 1]
+
+
+@pytest.mark.parametrize("bits", [False, True])
+def test_matmul_chunked_raster_order(ctx, monkeypatch, bits):
+    """qf_gemm_raster: chunks of message tiles run through every column tile; 19 message tiles in
+    chunks of 8 (a short last chunk), plain and packed-remainder kernels."""
+    monkeypatch.setenv("QF_GEMM_MCHUNK_BITS" if bits else "QF_GEMM_MCHUNK", "8")
+    B = 256 * 18 + 77
+    if bits:
+        n, m, q = 256, 200, 16777213
+        pk = co.sample_uniform(SEED, 1, 0, (n + 1) * m, q).reshape(n + 1, m)
+        xb = co.sample_bits(SEED, 3, 0, B, m, bit_stride(m))
+        msg = (co.sample_uniform(SEED, 5, 0, B, 2)).astype(np.uint8)
+        out = ctx.matmul(ctx.key_upload(pk, q), ctx.to_dev_u8(xb), X_BITS, B, msg=ctx.to_dev_u8(msg))
+        assert np.array_equal(ctx.to_host_u32(out), co.matmul_batch(pk, q, xb, co.X_BITS, B, msg=msg))
+    else:
+        n, q = 128, 1073741789
+        pk = co.sample_uniform(SEED, 1, 0, (n + 1) * n, q).reshape(n + 1, n)
+        r = co.sample_noise(SEED, 3, 0, B * n, q, 3000).reshape(B, n)
+        e = co.sample_noise(SEED, 4, 0, B * (n + 1), q, 3000).reshape(B, n + 1)
+        out = ctx.matmul(ctx.key_upload(pk, q), ctx.to_dev_u32(r), X_U32, B, addend=ctx.to_dev_u32(e), x_digits=2)
+        assert np.array_equal(ctx.to_host_u32(out), co.matmul_batch(pk, q, r, co.X_U32, B, addend=e))
