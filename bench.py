@@ -81,16 +81,30 @@ def parse():
     return ap.parse_args()
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+def _init_dist(world):
+    """One process per GPU, RCCL (backend "nccl").  QF_BENCH_REHEARSAL=1 is for rehearsing the
+    multi-process code path on a ONE-GPU box only: every rank uses cuda:0 and the collectives go
+    over gloo -- its numbers mean nothing."""
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    rehearsal = os.environ.get("QF_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    return local, dist
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local, dist = _init_dist(world)
 
     from crypto_amd.device import Context, X_BITS, bit_stride
     ctx = Context(local)
@@ -257,6 +271,8 @@ def main():
         out["cpu_baseline"] = None
 
     if rank == 0:
+        if os.environ.get("QF_BENCH_REHEARSAL") == "1":
+            out["rehearsal"] = "all ranks on cuda:0, collectives over gloo: not a measurement"
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
@@ -294,12 +310,7 @@ def other_workloads(args):
     """Configs 3-5 of BASELINE.json (not the headline line): same conventions, one JSON line."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    local, dist = _init_dist(world)
     from crypto_amd.device import Context, X_BITS, X_U32
     from crypto_amd import sharding
     ctx = Context(local)
@@ -472,6 +483,8 @@ def other_workloads(args):
                     "roofline": {"kernel": "qf_matvec_rows", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "launch_ms": ms}})
     if rank == 0:
+        if os.environ.get("QF_BENCH_REHEARSAL") == "1":
+            out["rehearsal"] = "all ranks on cuda:0, collectives over gloo: not a measurement"
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
