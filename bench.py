@@ -386,7 +386,7 @@ def other_workloads(args):
                     "ms_per_step": el / args.steps * 1e3, "dtype": "int8 digits (exact Z_q)",
                     "config": {"workload": "LPR enc (BASELINE config 4), r recoded to 2 signed digits (verified on device)",
                                "n": n, "q": q, "global_batch": Btot},
-                    "roofline": {"kernel": "qf_gemm_kernel<4,2,*,planes>", "bound": "mfma", "achieved": tops, "peak": INT8_PEAK_TOPS,
+                    "roofline": {"kernel": "qf_gemm_kernel<4,1,3,planes> (2 operand digits folded into the inner dimension)", "bound": "mfma", "achieved": tops, "peak": INT8_PEAK_TOPS,
                                  "unit": "TFLOP/s", "frac": tops / INT8_PEAK_TOPS, "traffic": None, "launch_ms": gemm_ms,
                                  "whole_call_ms": ms, "hbm_frac_whole_call": gbs / HBM_PEAK_GBS}})
     elif wl in ("ringlpr", "fdh"):

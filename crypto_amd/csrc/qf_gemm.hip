@@ -489,6 +489,26 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a, const uint32_t
         }
         const uint32_t krow = (rb0 + j) * 32 + (lane & 31);
         if (rb0 + j >= a.rb || krow >= a.rows) continue;
+        // addend: all 16 loads of the row block in flight at once (clamped addresses, no branch around
+        // them -- behind the per-element bounds branch every load was waited for on its own: LPR
+        // n=1024 2.9 -> 2.5 ms).  The packed kernels have no registers to spare for that and keep one
+        // load per element.
+        constexpr bool BATCH = !PACKED;
+        uint32_t add[BATCH ? 16 : 1];
+        const bool late_addend = a.addend != nullptr;
+        if constexpr (BATCH) {
+            if (late_addend) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    uint64_t mrow = (mb0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    mrow = mrow < a.B ? mrow : a.B - 1;
+                    add[r] = a.addend[mrow * a.rows + krow];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) add[r] = 0;
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const uint64_t mrow = (mb0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -500,7 +520,8 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a, const uint32_t
             int64_t x = 0;
 #pragma unroll
             for (int s = 0; s < S; s++) x += (int64_t)acc[i][j][s][r] * (int64_t)a.cs[s];
-            if (a.addend) x += (int64_t)a.addend[mrow * a.rows + krow];
+            if constexpr (BATCH) x += (int64_t)add[r];
+            else if (late_addend) x += (int64_t)a.addend[mrow * a.rows + krow];
             if (a.msg && krow == lastrow && (a.msg[mrow] & 1)) x += (int64_t)a.mod.qhalf;
             a.out[mrow * a.rows + krow] = qf_red_i64(x, a.mod);
         }

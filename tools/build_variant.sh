@@ -14,7 +14,7 @@ done
 wait
 # a GEMM kernel that spills must never run (see crypto_amd/csrc/Makefile): the NOLDS variant of the
 # digit-plane kernels does, and faulted the GPU when it was launched -- refuse such a build
-python3 $root/crypto_amd/csrc/check_noscratch.py $tmp/qf_gemm.remarks qf_gemm || { rm -rf $tmp; exit 1; }
+python3 $root/crypto_amd/csrc/check_noscratch.py $tmp/qf_gemm.remarks qf_gemm "$QF_ALLOW_SPILL" || { rm -rf $tmp; exit 1; }
 mkdir -p $root/tools/abl
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/tools/abl/libqfgpu_$name.so $tmp/*.o
 rm -rf $tmp

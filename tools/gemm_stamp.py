@@ -5,15 +5,27 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from crypto_amd.device import Context, X_BITS
 ctx = Context(0)
-n, m, q, B = 256, 6168, 16777213, 65536
-pk = ctx.sample_uniform(1, 1, 0, (n + 1) * m, q).view(n + 1, m)
-key = ctx.key_upload(pk, q)
-xb = ctx.sample_bits(1, 3, 0, B, m)
-nwaves = (B // 256) * 3 * 8
+if "lpr" in sys.argv[1:]:
+    from crypto_amd.device import X_U32
+    n, q, B = 1024, 1073741789, 1 << 17
+    pk = ctx.sample_uniform(1, 1, 0, (n + 1) * n, q).view(n + 1, n)
+    key = ctx.key_upload(pk, q)
+    r = ctx.sample_noise(1, 3, 0, B * n, q, 2319).view(B, n)
+    e = ctx.sample_noise(1, 4, 0, B * (n + 1), q, 2319).view(B, n + 1)
+    out = ctx.empty_u32(B, n + 1)
+    nwaves = (B // 256) * 11 * 8          # <4,1,3> tiles: 33 row blocks / 3
+    run = lambda: ctx.matmul(key, r, X_U32, B, addend=e, x_digits=2, out=out)
+else:
+    n, m, q, B = 256, 6168, 16777213, 65536
+    pk = ctx.sample_uniform(1, 1, 0, (n + 1) * m, q).view(n + 1, m)
+    key = ctx.key_upload(pk, q)
+    xb = ctx.sample_bits(1, 3, 0, B, m)
+    nwaves = (B // 256) * 3 * 8
+    run = lambda: ctx.matmul(key, xb, X_BITS, B)
 dbg = torch.zeros(nwaves * 8, dtype=torch.int64, device="cuda")
 ctx.lib.qf_debug_set_buffer(ctypes.c_void_p(dbg.data_ptr()))
 for _ in range(3):
-    out = ctx.matmul(key, xb, X_BITS, B)
+    run()
 torch.cuda.synchronize()
 d = dbg.cpu().numpy().reshape(nwaves, 8)
 tot = (d[:, 6] - d[:, 5]).mean()
