@@ -385,6 +385,20 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a, const uint32_t
     QF_LOAD_AT(0, 0)
     QF_STAGE(0, 0)
     QF_STAGE(ntiles > 1 ? 1 : 0, 1)
+    // message bits of this wave's MW*32 messages as one 32-bit mask per block (SGPRs), loaded here so
+    // that the wait merges with the prologue's drain; only tiles that hold the key's last row need it
+    // (the epilogue used to load one byte per element there, each load waited for on its own)
+    uint32_t msgmask[MW];
+#pragma unroll
+    for (int i = 0; i < MW; i++) msgmask[i] = 0;
+    if (a.msg && (uint64_t)(rb0 + WN) * 32 >= a.rows) {
+#pragma unroll
+        for (int i = 0; i < MW; i++) {
+            const uint64_t mrow_l = (mb0 + i) * 32 + (lane & 31);
+            const bool bit = lane < 32 && mrow_l < a.B && (a.msg[mrow_l < a.B ? mrow_l : 0] & 1);
+            msgmask[i] = (uint32_t)__ballot(bit);
+        }
+    }
     QF_WAIT_AT(0, 0)
     __syncthreads();  // drains the DMA (vmcnt(0)) and synchronises the workgroup
     if constexpr (PF) {
@@ -482,7 +496,7 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a, const uint32_t
                 for (int l = 0; l < LA; l++)
                     x += (int64_t)__shfl(acc[i][j][0][r], (int)(lane - l0 + l), 64) * (int64_t)a.cs[l];
                 if (!owner || mrow >= a.B) continue;
-                if (a.msg && krow == lastrow && (a.msg[mrow] & 1)) x += (int64_t)a.mod.qhalf;
+                if (krow == lastrow && ((msgmask[i] >> ((r & 3) + 8 * (r >> 2) + 4 * h)) & 1)) x += (int64_t)a.mod.qhalf;
                 a.out[mrow * a.rows + krow] = qf_red_i64(x, a.mod);
             }
             continue;
@@ -522,7 +536,7 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a, const uint32_t
             for (int s = 0; s < S; s++) x += (int64_t)acc[i][j][s][r] * (int64_t)a.cs[s];
             if constexpr (BATCH) x += (int64_t)add[r];
             else if (late_addend) x += (int64_t)a.addend[mrow * a.rows + krow];
-            if (a.msg && krow == lastrow && (a.msg[mrow] & 1)) x += (int64_t)a.mod.qhalf;
+            if (krow == lastrow && ((msgmask[i] >> ((r & 3) + 8 * (r >> 2) + 4 * h)) & 1)) x += (int64_t)a.mod.qhalf;
             a.out[mrow * a.rows + krow] = qf_red_i64(x, a.mod);
         }
     }
