@@ -703,6 +703,8 @@ static int qf_key_fold(qf_ctx *ctx, const qf_key *key, int lb) {
         if (rc) { hipFree(planes); return rc; }
         mult = (mult * 256) % key->q;
     }
+    // the planes must be complete before another context (another stream) can find them
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { hipFree(planes); return qf_fail(ctx, QF_ERR_DEVICE, "folded key planes: recode failed"); }
     key->fold_planes[lb] = planes;
     return QF_OK;
 }

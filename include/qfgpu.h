@@ -19,6 +19,10 @@
  *   - A context is bound to one device and one stream and is not re-entrant; work is
  *     enqueued on the context's stream.  *_dev entry points are asynchronous w.r.t. the
  *     host unless stated; *_host entry points synchronise before returning.
+ *   - A key handle may be shared by contexts of the same device but not used by two of them
+ *     at the same time: the first product with an L-digit batch operand (L >= 2) attaches a
+ *     second, L times larger set of digit planes to it (one allocation, kept until
+ *     qf_key_destroy).
  */
 #ifndef QFGPU_H
 #define QFGPU_H
