@@ -301,6 +301,14 @@ static void fill_common(QfRingArgs &a, const qf_ring *ring, uint64_t B) {
     a.one_p = (uint32_t)((1ull << 32) / ring->q);
     a.off32 = (uint32_t)((((1ull << 31) + ring->q - 1) / ring->q) * ring->q);
     a.u = nullptr; a.ok = nullptr; a.norm_bound = 0;
+    a.qinv32 = 0; a.ninv_m = 0; a.ninv_m_p = 0;
+    if (ring->q & 1) {
+        uint32_t inv = ring->q;                       // Newton: q*inv == 1 mod 2^32 after 5 steps (q odd)
+        for (int i = 0; i < 5; i++) inv *= 2u - ring->q * inv;
+        a.qinv32 = inv;
+        a.ninv_m = (uint32_t)(((uint64_t)ring->ninv << 32) % ring->q);
+        a.ninv_m_p = (uint32_t)((((uint64_t)a.ninv_m) << 32) / ring->q);
+    }
 }
 template <int MODE>
 static int launch_ring(qf_ctx *ctx, const qf_ring *ring, const QfRingArgs &a) {

@@ -229,12 +229,24 @@ __global__ __launch_bounds__(WV_THREADS) void qf_ring_wave_kernel(QfRingArgs a) 
             load_nat(xb, a.in1 + item * N);
             W::forward(xa, lane, buf, twf, twg_f, q);
             W::forward(xb, lane, buf, twf, twg_f, q);
+            // pointwise product in Montgomery form: a*b*2^-32 mod q with 4 multiplies (a 64-bit Barrett
+            // product takes 10); the 2^-32 is absorbed by the final n^-1 scaling (ninv_m = n^-1 * 2^32).
+            // a is canonicalised so that a*b < q*2^32 (b < 4q, q < 2^30 in the lazy variant).
 #pragma unroll
-            for (int r = 0; r < R; r++) xa[r] = qf_mulmod(xa[r], xb[r], a.mod);
+            for (int r = 0; r < R; r++) {
+                uint32_t va = xa[r];
+                if (LAZY) { va = min(va, va - q2); va = min(va, va - q); }
+                const uint32_t lo = va * xb[r], hi = __umulhi(va, xb[r]);
+                const uint32_t v = hi - __umulhi(lo * a.qinv32, q) + q;   // (0, 2q)
+                xa[r] = LAZY ? v : min(v, v - q);
+            }
             W::inverse(xa, lane, buf, twi, twg_i, q);
             uint32_t *dst = a.out0 + item * N;
 #pragma unroll
-            for (int r = 0; r < R; r++) dst[lane + 64 * r] = finish(xa[r]);
+            for (int r = 0; r < R; r++) {
+                const uint32_t t = xa[r] * a.ninv_m - __umulhi(xa[r], a.ninv_m_p) * q;
+                dst[lane + 64 * r] = min(t, t - q);
+            }
         } else if constexpr (MODE == MODE_FWD_ONLY) {
             // key preparation: interleaved (value, Shoup companion) pairs in last-phase register order
             uint32_t x[R];

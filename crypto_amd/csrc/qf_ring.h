@@ -22,6 +22,9 @@ struct QfRingArgs {
     // wave kernel (qf_ntt_wave.hip) only
     uint32_t one_p;                   // floor(2^32 / q): Shoup companion of 1 (cheap 32-bit reduction)
     uint32_t off32;                   // smallest multiple of q that is >= 2^31 (signed -> unsigned shift)
+    // Montgomery pointwise product of the wave kernel's POLYMUL mode (q odd): q^-1 mod 2^32, and
+    // n^-1 * 2^32 mod q with its Shoup companion (the final scaling absorbs the 2^-32 of the product)
+    uint32_t qinv32, ninv_m, ninv_m_p;
     const uint32_t *u;                // FDH: hashed targets (B x n)
     uint8_t *ok;                      // FDH: verdicts
     uint64_t norm_bound;              // FDH: floor(s^2 * n * mbar)
