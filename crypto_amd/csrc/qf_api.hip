@@ -110,6 +110,7 @@ void qf_ctx_destroy(qf_ctx *ctx) {
     if (ctx->ws) hipFree(ctx->ws);
     if (ctx->ws2) hipFree(ctx->ws2);
     if (ctx->flag) hipFree(ctx->flag);
+    if (ctx->cdt) hipFree(ctx->cdt);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -516,6 +517,48 @@ int qf_sample_noise_dev(qf_ctx *ctx, uint64_t seed, uint32_t stream, uint64_t fi
     if (W >= (1u << 30)) return qf_fail(ctx, QF_ERR_ARG, "sample noise: W too large");
     QF_BIND(ctx);
     return qf_launch_sample_noise(ctx, gen_base(seed, stream), first, count, qf_make_mod(q), W, out_dev);
+}
+
+// D_{Z,s}: rho_s(x) = exp(-pi x^2 / s^2) on |x| <= T = ceil(s * log2(n)) (GPV08 SampleZ's support with
+// t = log2 n), as thresholds floor(2^64 * cumulative / total); sums run in long double from -T up.
+static int build_cdt(qf_ctx *ctx, uint32_t n, double s) {
+    if (ctx->cdt && ctx->cdt_n == n && ctx->cdt_s == s) return QF_OK;
+    const long double sl = (long double)s;
+    const long double Tl = ceill(sl * log2l((long double)n));
+    if (!(Tl >= 1.0L) || Tl > (long double)(1 << 21)) return qf_fail(ctx, QF_ERR_NOTSUP, "discrete gauss: support s*log2(n) must be in [1, 2^21]");
+    const int64_t T = (int64_t)Tl;
+    const size_t len = (size_t)(2 * T + 1);
+    std::vector<long double> cum(len);
+    const long double pi = 3.14159265358979323846264338327950288L;
+    long double acc = 0.0L;
+    for (int64_t x = -T; x <= T; x++) {
+        acc += expl(-pi * (long double)x * (long double)x / (sl * sl));
+        cum[(size_t)(x + T)] = acc;
+    }
+    std::vector<uint64_t> thr(len);
+    for (size_t i = 0; i < len; i++) {
+        const long double f = cum[i] / acc * 18446744073709551616.0L;
+        thr[i] = f >= 18446744073709551615.0L ? 0xFFFFFFFFFFFFFFFFull : (uint64_t)f;
+    }
+    thr[len - 1] = 0xFFFFFFFFFFFFFFFFull;
+    QF_HIP(ctx, hipStreamSynchronize(ctx->stream));   // a sampler launch may still read the old table
+    if (ctx->cdt) { hipFree(ctx->cdt); ctx->cdt = nullptr; }
+    QF_HIP(ctx, hipMalloc((void **)&ctx->cdt, len * 8));
+    QF_HIP(ctx, hipMemcpy(ctx->cdt, thr.data(), len * 8, hipMemcpyHostToDevice));
+    ctx->cdt_len = (uint32_t)len; ctx->cdt_n = n; ctx->cdt_s = s;
+    return QF_OK;
+}
+int qf_sample_discrete_gauss_dev(qf_ctx *ctx, uint64_t seed, uint32_t stream, uint64_t first, uint64_t count, uint32_t q,
+                                 uint32_t n, double s, uint32_t *out_dev) {
+    if (!ctx || (!out_dev && count)) return QF_ERR_ARG;
+    int rc = check_q(ctx, q);
+    if (rc) return rc;
+    if (n < 2 || !(s > 0.0)) return qf_fail(ctx, QF_ERR_ARG, "discrete gauss: need n >= 2 and s > 0");
+    QF_BIND(ctx);
+    rc = build_cdt(ctx, n, s);
+    if (rc) return rc;
+    return qf_launch_sample_cdt(ctx, gen_base(seed, stream), first, count, qf_make_mod(q), ctx->cdt, ctx->cdt_len,
+                                -(int64_t)(ctx->cdt_len / 2), out_dev);
 }
 
 // ------------------------------------------------------------------ timing

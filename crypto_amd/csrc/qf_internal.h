@@ -16,6 +16,10 @@ struct qf_ctx {
     void *ws2 = nullptr;      // mat-vec partial sums / small staging
     size_t ws2_bytes = 0;
     uint32_t *flag = nullptr; // device error flag (range violations)
+    // discrete-Gaussian inversion table of the last (n, s) asked for (qf_sample_discrete_gauss_dev)
+    uint64_t *cdt = nullptr;
+    uint32_t cdt_len = 0, cdt_n = 0;
+    double cdt_s = 0.0;
     // timing
     int timing = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -100,6 +104,8 @@ int qf_launch_dot_decode(qf_ctx *ctx, const uint32_t *w, uint32_t n, const QfMod
 int qf_launch_sample_uniform(qf_ctx *ctx, uint64_t base, uint64_t first, uint64_t count, uint32_t q, uint32_t *out);
 int qf_launch_sample_bits(qf_ctx *ctx, uint64_t base, uint64_t first_row, uint64_t rows, uint32_t cols,
                           uint32_t stride_bytes, uint8_t *out);
+int qf_launch_sample_cdt(qf_ctx *ctx, uint64_t base, uint64_t first, uint64_t count, const QfMod &mod,
+                         const uint64_t *thr_dev, uint32_t len, int64_t lo, uint32_t *out);
 int qf_launch_sample_noise(qf_ctx *ctx, uint64_t base, uint64_t first, uint64_t count, const QfMod &mod,
                            uint32_t W, uint32_t *out);
 // qf_ntt.hip

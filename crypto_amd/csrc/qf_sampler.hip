@@ -39,6 +39,24 @@ __global__ void qf_sample_noise_kernel(uint64_t base, uint64_t first, uint64_t c
     }
 }
 
+// Discrete Gaussian D_{Z,s} (center 0) by inversion: thr[i] = floor(2^64 * P[X <= lo + i]) built on the
+// host (qf_api.hip, build_cdt), one 64-bit draw per sample, x = lo + #{i : thr[i] <= v}.
+__global__ void qf_sample_cdt_kernel(uint64_t base, uint64_t first, uint64_t count, QfMod mod,
+                                     const uint64_t *__restrict__ thr, uint32_t len, int64_t lo,
+                                     uint32_t *__restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < count; i += stride) {
+        const uint64_t v = qf_rand64(base, first + i);
+        uint32_t a = 0, b = len - 1;          // smallest index with thr[idx] > v; thr[len-1] = 2^64-1 ends the search
+        while (a < b) {
+            const uint32_t m = (a + b) >> 1;
+            if (thr[m] > v) b = m; else a = m + 1;
+        }
+        out[i] = qf_red_i64(lo + (int64_t)a, mod);
+    }
+}
+
 static unsigned sampler_grid(uint64_t n) {
     uint64_t b = (n + 255) / 256;
     return (unsigned)(b > 256 * 32 ? 256 * 32 : (b ? b : 1));
@@ -60,6 +78,13 @@ int qf_launch_sample_bits(qf_ctx *ctx, uint64_t base, uint64_t first_row, uint64
 int qf_launch_sample_noise(qf_ctx *ctx, uint64_t base, uint64_t first, uint64_t count, const QfMod &mod, uint32_t W, uint32_t *out) {
     if (!count) return QF_OK;
     hipLaunchKernelGGL(qf_sample_noise_kernel, dim3(sampler_grid(count)), dim3(256), 0, ctx->stream, base, first, count, mod, W, out);
+    QF_HIP(ctx, hipGetLastError());
+    return QF_OK;
+}
+int qf_launch_sample_cdt(qf_ctx *ctx, uint64_t base, uint64_t first, uint64_t count, const QfMod &mod,
+                         const uint64_t *thr_dev, uint32_t len, int64_t lo, uint32_t *out) {
+    if (!count) return QF_OK;
+    hipLaunchKernelGGL(qf_sample_cdt_kernel, dim3(sampler_grid(count)), dim3(256), 0, ctx->stream, base, first, count, mod, thr_dev, len, lo, out);
     QF_HIP(ctx, hipGetLastError());
     return QF_OK;
 }

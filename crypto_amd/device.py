@@ -209,6 +209,13 @@ class Context:
         _check(self.h, self.lib.qf_sample_noise_dev(self.h, seed, stream, first, count, q, W, out.data_ptr()))
         return out
 
+    def sample_discrete_gauss(self, seed, stream, first, count, q, n, s, out=None):
+        """D_{Z,s} (center 0) mod q, the distribution of MatZq::sample_discrete_gauss(.., q, n, 0, s)
+        (regev.rs:356-363, lpr.rs:342-360): seeded, drawn on the device."""
+        out = out if out is not None else self.empty_u32(count)
+        _check(self.h, self.lib.qf_sample_discrete_gauss_dev(self.h, seed, stream, first, count, q, int(n), float(s), out.data_ptr()))
+        return out
+
 
 class Key:
     """A MatZq resident on the device (qf_key)."""

@@ -194,6 +194,17 @@ int qf_sample_bits_dev(qf_ctx *ctx, uint64_t seed, uint32_t stream, uint64_t fir
 int qf_sample_noise_dev(qf_ctx *ctx, uint64_t seed, uint32_t stream, uint64_t first, uint64_t count,
                         uint32_t q, uint32_t W, uint32_t *out_dev);
 
+/* Discrete Gaussian over Z with center 0 and Gaussian parameter s, stored mod q -- the distribution
+ * of MatZq::sample_discrete_gauss(rows, cols, q, n, 0, s) at the reference's call sites
+ * (pk_encryption/regev.rs:356-363, lpr.rs:342-360,399-417, ring_lpr.rs:430-452): rho_s(x) =
+ * exp(-pi x^2 / s^2) on the support |x| <= ceil(s*log2(n)) of GPV08 SampleZ.  Sampled by inversion:
+ * sample idx is the x whose cumulative-probability threshold floor(2^64 * P[X <= x]) is the first one
+ * above the generator's 64-bit value(stream, first + i).  The table (long double sums from -T up) is
+ * built on the host and cached in the context.  Parity with the reference is distributional only
+ * (its RNG is unseeded); oracle/qf_oracle.c restates the same table and draw. */
+int qf_sample_discrete_gauss_dev(qf_ctx *ctx, uint64_t seed, uint32_t stream, uint64_t first, uint64_t count,
+                                 uint32_t q, uint32_t n, double s, uint32_t *out_dev);
+
 /* ------------------------------------------------------------------ introspection for benches
  * Average duration (ms) of the LAST launch of the dominant kernel of the named op, measured
  * with HIP events on the context's stream when timing is enabled. */

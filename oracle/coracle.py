@@ -65,6 +65,15 @@ def sample_noise(seed, stream, first, count, q, W):
     return out
 
 
+def sample_discrete_gauss(seed, stream, first, count, q, n, s):
+    out = np.empty(count, np.uint32)
+    rc = lib().qfo_sample_discrete_gauss(C.c_uint64(seed), C.c_uint32(stream), C.c_uint64(first),
+                                         C.c_uint64(count), C.c_uint32(q), C.c_uint32(n), C.c_double(s), _p(out))
+    if rc:
+        raise ValueError("discrete gauss: support s*log2(n) outside [1, 2^21]")
+    return out
+
+
 def sample_bits(seed, stream, first_row, rows, cols, stride_bytes):
     out = np.empty((rows, stride_bytes), np.uint8)
     lib().qfo_sample_bits(C.c_uint64(seed), C.c_uint32(stream), C.c_uint64(first_row),

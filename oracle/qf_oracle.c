@@ -102,6 +102,45 @@ void qfo_sample_noise(uint64_t seed, uint32_t stream, uint64_t first, uint64_t c
     }
 }
 
+/* Discrete Gaussian D_{Z,s}, center 0, stored mod q: the distribution of the reference's
+ * MatZq::sample_discrete_gauss(.., q, n, 0, s) (regev.rs:356-363, lpr.rs:342-360,399-417,
+ * ring_lpr.rs:430-452) -- rho_s(x) = exp(-pi x^2/s^2) on |x| <= ceil(s*log2 n) -- drawn by
+ * inversion from ONE 64-bit generator value per sample: x = -T + #{i : thr_i <= v},
+ * thr_i = floor(2^64 * P[X <= -T+i]).  Parity with the reference is distributional only (its
+ * RNG is unseeded and qfall-math's sampler is not in /root/reference): "parity unpinned". */
+#include <math.h>
+int qfo_sample_discrete_gauss(uint64_t seed, uint32_t stream, uint64_t first, uint64_t count,
+                              uint32_t q, uint32_t n, double s, uint32_t *out) {
+    long double sl = (long double)s;
+    long double Tl = ceill(sl * log2l((long double)n));
+    if (!(Tl >= 1.0L) || Tl > 2097152.0L) return 1;
+    int64_t T = (int64_t)Tl;
+    size_t len = (size_t)(2 * T + 1);
+    long double *cum = (long double *)malloc(len * sizeof(long double));
+    uint64_t *thr = (uint64_t *)malloc(len * sizeof(uint64_t));
+    const long double pi = 3.14159265358979323846264338327950288L;
+    long double tot = 0.0L;
+    for (int64_t x = -T; x <= T; x++) {
+        tot += expl(-pi * (long double)x * (long double)x / (sl * sl));
+        cum[x + T] = tot;
+    }
+    for (size_t i = 0; i < len; i++) {
+        long double f = cum[i] / tot * 18446744073709551616.0L;
+        thr[i] = f >= 18446744073709551615.0L ? UINT64_MAX : (uint64_t)f;
+    }
+    thr[len - 1] = UINT64_MAX;
+    for (uint64_t i = 0; i < count; i++) {
+        uint64_t v = qfo_rand64(seed, stream, first + i);
+        size_t a = 0, b = len - 1;          /* smallest index whose threshold exceeds v */
+        while (a < b) { size_t m = (a + b) / 2; if (thr[m] > v) b = m; else a = m + 1; }
+        int64_t r = ((int64_t)a - T) % (int64_t)q;
+        if (r < 0) r += q;
+        out[i] = (uint32_t)r;
+    }
+    free(cum); free(thr);
+    return 0;
+}
+
 /* ------------------------------------------------ Z_q matrix products (kernels a, c) */
 
 /* y = A*x mod q, A rows x cols, x in Z_q^cols.

@@ -305,3 +305,32 @@ def test_matmul_chunked_raster_order(ctx, monkeypatch, bits):
         e = co.sample_noise(SEED, 4, 0, B * (n + 1), q, 3000).reshape(B, n + 1)
         out = ctx.matmul(ctx.key_upload(pk, q), ctx.to_dev_u32(r), X_U32, B, addend=ctx.to_dev_u32(e), x_digits=2)
         assert np.array_equal(ctx.to_host_u32(out), co.matmul_batch(pk, q, r, co.X_U32, B, addend=e))
+
+
+@pytest.mark.parametrize("q,n,s", [(983, 10, 983 * 0.0072), (1073741789, 1024, 1073741789 * 6.25e-6), (16777213, 256, 3000.5), (7, 2, 40.0)])
+def test_discrete_gauss_sampler(ctx, q, n, s):
+    """qf_sample_discrete_gauss_dev: bit-identical to the oracle's inversion sampler, and distributed as
+    D_{Z,s}: support |x| <= ceil(s log2 n), mean 0, variance s^2/(2 pi), per-value frequencies (chi-square
+    against exp(-pi x^2/s^2)).  Parity with the reference is distributional only (its RNG is unseeded)."""
+    N = 400000
+    d = ctx.to_host_u32(ctx.sample_discrete_gauss(SEED, 4, 123, N, q, n, s))
+    assert np.array_equal(d, co.sample_discrete_gauss(SEED, 4, 123, N, q, n, s))
+    if q < 4 * s * np.log2(n):
+        return                                   # wraps around mod q: only the parity check applies
+    x = d.astype(np.int64)
+    x[x > q // 2] -= q
+    T = int(np.ceil(s * np.log2(n)))
+    assert np.abs(x).max() <= T
+    sigma = s / np.sqrt(2 * np.pi)
+    assert abs(x.mean()) < 5 * sigma / np.sqrt(N)
+    assert abs(x.var() / sigma ** 2 - 1) < 0.02
+    # chi-square over 40 equiprobable-ish bins of width sigma/4 around 0
+    edges = np.arange(-20, 21) * max(1, int(round(sigma / 4)))
+    support = np.arange(-T, T + 1)
+    pmf = np.exp(-np.pi * support.astype(np.float64) ** 2 / s ** 2)
+    pmf /= pmf.sum()
+    exp = np.array([pmf[(support >= a) & (support < b)].sum() for a, b in zip(edges[:-1], edges[1:])]) * N
+    obs = np.histogram(x, bins=edges)[0]
+    keep = exp > 50
+    chi2 = (((obs - exp) ** 2) / exp)[keep].sum()
+    assert chi2 < keep.sum() + 6 * np.sqrt(2 * keep.sum()), (chi2, keep.sum())

@@ -188,3 +188,19 @@ def test_fixed_classical_trapdoor_kat():
         assert po.matvec(A.tolist(), col.tolist(), q) == G[:, j].tolist()
     cols = np.ascontiguousarray(T.T).astype(np.int32)                               # 6 "messages" of 13 entries
     assert np.array_equal(co.matmul_batch(A, q, cols, co.X_I32, 6), G.T)
+
+
+def test_oracle_discrete_gauss_distribution():
+    """The oracle's inversion sampler draws D_{Z,s}: support, mean, variance s^2/(2 pi).  (Parity with the
+    reference's sampler is distributional only -- its RNG is unseeded, qfall-math is not in the tree.)"""
+    q, n, s, N = 1073741789, 1024, 1073741789 * 6.25e-6, 200000
+    x = co.sample_discrete_gauss(SEED, 4, 0, N, q, n, s).astype(np.int64)
+    x[x > q // 2] -= q
+    sigma = s / np.sqrt(2 * np.pi)
+    assert np.abs(x).max() <= int(np.ceil(s * np.log2(n)))
+    assert abs(x.mean()) < 5 * sigma / np.sqrt(N)
+    assert abs(x.var() / sigma ** 2 - 1) < 0.02
+    # consecutive windows of one stream are consistent (counter mode)
+    assert np.array_equal(co.sample_discrete_gauss(SEED, 4, 100, 50, q, n, s), co.sample_discrete_gauss(SEED, 4, 0, 150, q, n, s)[100:])
+    with pytest.raises(ValueError):
+        co.sample_discrete_gauss(SEED, 4, 0, 1, q, 1024, 1e7)      # support beyond 2^21
