@@ -10,9 +10,10 @@ from ...runtime import Randomness, default_context
 
 
 class MatrixSchemeMixin:
-    def _init_runtime(self, ctx=None, seed=None):
+    def _init_runtime(self, ctx=None, seed=None, noise_model=None):
         self._ctx = ctx
         self.rng = Randomness(seed, ctx) if seed is not None else Randomness(ctx=ctx)
+        set_noise_model(self, noise_model)
 
     @property
     def ctx(self):
@@ -41,6 +42,17 @@ class MatrixSchemeMixin:
         c = ciphers if not isinstance(ciphers, np.ndarray) else self.ctx.to_dev_u32(ciphers)
         bits = self.ctx.dot_decode(self.ctx.to_dev_u32(w), self.q, c)
         return self.ctx.to_host_u8(bits)
+
+
+def set_noise_model(scheme, noise_model):
+    """noise_model: None / "irwin_hall" (the seeded benchmark generator's stand-in) or "discrete_gauss"
+    (D_{Z, alpha*q} with security parameter n, as the reference samples chi: regev.rs:356-363)."""
+    if noise_model in (None, "irwin_hall"):
+        scheme.rng.gauss = None
+    elif noise_model == "discrete_gauss":
+        scheme.rng.gauss = (int(scheme.n), float(scheme.alpha * getattr(scheme, "q_int", scheme.q)))
+    else:
+        raise ValueError("noise_model must be 'irwin_hall' or 'discrete_gauss'")
 
 
 def message_bit(message) -> int:

@@ -59,7 +59,7 @@ class DualRegev(Regev):
             s = ctx.to_dev_u32(s)
         if e is None:
             cnt = B * (self.m + 1)
-            e = ctx.sample_noise(self.rng.seed, 4, self.rng._take(4, cnt), cnt, q, self.noise_width).view(B, self.m + 1)
+            e = self.rng.noise_dev(4, cnt, q, self.noise_width).view(B, self.m + 1)
         elif isinstance(e, np.ndarray):
             e = ctx.to_dev_u32(e)
         return ctx.matmul(self._dev_key(pk, transpose=True), s, X_U32, B, addend=e, msg=ctx.to_dev_u8(msg))

@@ -18,12 +18,12 @@ def _factor(n: int) -> int:
 
 
 class LPR(MatrixSchemeMixin, GenericMultiBitEncryption):
-    def __init__(self, n, q, alpha, ctx=None, seed=None):
+    def __init__(self, n, q, alpha, ctx=None, seed=None, noise_model=None):
         self.n, self.q = int(n), int(q)
         if self.q <= 1:
             raise ValueError("modulus must be > 1")
         self.alpha = as_fraction(alpha)
-        self._init_runtime(ctx, seed)
+        self._init_runtime(ctx, seed, noise_model)
 
     new = classmethod(lambda cls, n, q, alpha, **kw: cls(n, q, alpha, **kw))
 
@@ -79,8 +79,8 @@ class LPR(MatrixSchemeMixin, GenericMultiBitEncryption):
 
     @property
     def noise_digits(self) -> int:
-        """signed 8-bit digits that cover the generator's noise range |v| <= 4W (0 = full width)."""
-        bound = 4 * self.noise_width
+        """signed 8-bit digits that cover the noise model's range (4W, or ceil(s log2 n) for D_{Z,s})."""
+        bound = self.rng.noise_bound(self.noise_width)
         d = 1
         while 127 * (256 ** d - 1) // 255 < bound:
             d += 1
@@ -120,11 +120,11 @@ class LPR(MatrixSchemeMixin, GenericMultiBitEncryption):
         msg = np.array([message_bit(v) for v in np.asarray(messages).reshape(-1)], np.uint8)
         B = msg.size
         if r is None:
-            r = ctx.sample_noise(self.rng.seed, 3, self.rng._take(3, B * self.n), B * self.n, q, W).view(B, self.n)
+            r = self.rng.noise_dev(3, B * self.n, q, W).view(B, self.n)
         elif isinstance(r, np.ndarray):
             r = ctx.to_dev_u32(r)
         if e is None:
-            e = ctx.sample_noise(self.rng.seed, 4, self.rng._take(4, B * (self.n + 1)), B * (self.n + 1), q, W).view(B, self.n + 1)
+            e = self.rng.noise_dev(4, B * (self.n + 1), q, W).view(B, self.n + 1)
         elif isinstance(e, np.ndarray):
             e = ctx.to_dev_u32(e)
         return ctx.matmul(self._dev_key(pk), r, X_U32, B, addend=e, msg=ctx.to_dev_u8(msg), x_digits=self.noise_digits)

@@ -19,13 +19,13 @@ from .base import GenericMultiBitEncryption, largest_prime_at_most
 
 
 class Regev(MatrixSchemeMixin, GenericMultiBitEncryption):
-    def __init__(self, n, m, q, alpha, ctx=None, seed=None):
+    def __init__(self, n, m, q, alpha, ctx=None, seed=None, noise_model=None):
         """Regev::new (regev.rs:87-99).  Parameters are not checked (as in the reference)."""
         self.n, self.m, self.q = int(n), int(m), int(q)
         if self.q <= 1:
             raise ValueError("modulus must be > 1")
         self.alpha = as_fraction(alpha)
-        self._init_runtime(ctx, seed)
+        self._init_runtime(ctx, seed, noise_model)
 
     new = classmethod(lambda cls, n, m, q, alpha, **kw: cls(n, m, q, alpha, **kw))
 

@@ -12,10 +12,11 @@ from ...runtime import Randomness, default_context
 from ...utils.common_moduli import new_anticyclic
 from .base import PKEncryptionScheme, largest_prime_at_most
 from .lpr import _factor
+from ._matrix_scheme import set_noise_model
 
 
 class RingLPR(PKEncryptionScheme):
-    def __init__(self, n, q, alpha, ctx=None, seed=None):
+    def __init__(self, n, q, alpha, ctx=None, seed=None, noise_model=None):
         """RingLPR::new (ring_lpr.rs:90-104): modulus (X^n + 1) mod q."""
         self.n, self.q_int = int(n), int(q)
         self.q = new_anticyclic(self.n, self.q_int)
@@ -23,6 +24,7 @@ class RingLPR(PKEncryptionScheme):
         self._ctx = ctx
         self.rng = Randomness(seed, ctx) if seed is not None else Randomness(ctx=ctx)
         self._ring = None
+        set_noise_model(self, noise_model)
 
     new = classmethod(lambda cls, n, q, alpha, **kw: cls(n, q, alpha, **kw))
 
@@ -117,7 +119,7 @@ class RingLPR(PKEncryptionScheme):
 
         def draw(stream, given):
             if given is None:
-                return ctx.sample_noise(self.rng.seed, stream, self.rng._take(stream, B * n), B * n, q, W).view(B, n)
+                return self.rng.noise_dev(stream, B * n, q, W).view(B, n)
             return ctx.to_dev_u32(given) if isinstance(given, np.ndarray) else given
         r, e1, e2 = draw(3, r), draw(4, e1), draw(4, e2)
         pk_key = self.ring.key(np.stack([pk[0].coeffs, pk[1].coeffs]))

@@ -54,9 +54,28 @@ class Randomness:
         first = self._take(stream, count)
         return self.ctx.to_host_u32(self.ctx.sample_uniform(self.seed, stream, first, count, q))
 
-    def noise(self, stream: int, count: int, q: int, W: int) -> np.ndarray:
+    # Noise model of chi: "irwin_hall" (default) = the benchmark generator's Gaussian stand-in of
+    # SURVEY 8d, sum of 4 uniforms in [-W, W]; "discrete_gauss" = D_{Z,s} with the reference's
+    # parameters (n, s = alpha*q) -- what MatZq::sample_discrete_gauss(.., q, n, 0, s) draws
+    # (regev.rs:356-363).  Set through the schemes' noise_model argument.
+    gauss = None    # (n, s) when the model is "discrete_gauss"
+
+    def noise_dev(self, stream: int, count: int, q: int, W: int):
+        """count draws from chi as a device tensor (canonical residues mod q)."""
         first = self._take(stream, count)
-        return self.ctx.to_host_u32(self.ctx.sample_noise(self.seed, stream, first, count, q, W))
+        if self.gauss is not None:
+            return self.ctx.sample_discrete_gauss(self.seed, stream, first, count, q, self.gauss[0], self.gauss[1])
+        return self.ctx.sample_noise(self.seed, stream, first, count, q, W)
+
+    def noise(self, stream: int, count: int, q: int, W: int) -> np.ndarray:
+        return self.ctx.to_host_u32(self.noise_dev(stream, count, q, W))
+
+    def noise_bound(self, W: int) -> int:
+        """largest |value| chi can produce under the current model"""
+        if self.gauss is not None:
+            import math
+            return int(math.ceil(self.gauss[1] * math.log2(self.gauss[0])))
+        return 4 * W
 
     def bits(self, stream: int, count: int) -> np.ndarray:
         """count independent bits as a 0/1 uint32 vector (MatZ::sample_uniform(m,1,0,2))."""

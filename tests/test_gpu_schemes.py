@@ -224,3 +224,35 @@ def test_fdh_ring_vfy(ctx):
     sg = np.stack([s.entries for s in sigs]).astype(np.int32)
     _, ok_ref = co.fdh_ring_verify_batch(pk, q, sg, u_all, fdh.psf.norm_bound())
     assert ok_ref.tolist() == [1] * 10
+
+
+@pytest.mark.parametrize("make", [Regev.default, lambda **k: Regev.new_from_n(50, **k), LPR.default,
+                                  lambda **k: LPR.new_from_n(64, **k), lambda **k: DualRegev.new_from_n(20, **k),
+                                  lambda **k: RingLPR.new_from_n(64, **k)])
+def test_cycle_with_discrete_gaussian_noise(ctx, make):
+    """The same round trips with chi = D_{Z, alpha*q} drawn on the device, the distribution the reference
+    samples (regev.rs:356-363, lpr.rs:342-360,399-417, ring_lpr.rs:430-452) instead of the benchmark
+    generator's stand-in: single messages and a batch decrypt to what was encrypted."""
+    scheme = make(ctx=ctx, noise_model="discrete_gauss")
+    assert scheme.rng.gauss is not None
+    pk, sk = scheme.gen()
+    if isinstance(scheme, RingLPR):
+        msgs = [0, 1, 5, (1 << scheme.n) - 1]
+        for m in msgs:
+            assert scheme.dec(sk, scheme.enc(pk, m)) == m
+        return
+    for msg in (0, 1, 1, 0):
+        assert scheme.dec(sk, scheme.enc(pk, msg)) == msg
+    msgs = np.arange(300) % 2
+    assert scheme.dec_batch(sk, scheme.enc_batch(pk, msgs)).tolist() == msgs.tolist()
+
+
+def test_lpr_noise_digits_follow_the_model(ctx):
+    s = LPR.new_from_n(1024, ctx=ctx)
+    assert s.noise_digits == 2
+    g = LPR.new_from_n(1024, ctx=ctx, noise_model="discrete_gauss")
+    import math
+    assert g.rng.noise_bound(g.noise_width) == math.ceil(float(g.alpha * g.q) * 10)
+    assert g.noise_digits in (2, 3)
+    with pytest.raises(ValueError):
+        LPR.default(ctx=ctx, noise_model="binomial")
