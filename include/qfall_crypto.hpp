@@ -150,9 +150,17 @@ class Randomness {
         dev_->check(qf_sample_uniform_dev(dev_->ctx(), seed_, stream, take(stream, count), count, q, b.get()));
         return b.download();
     }
+    // chi: the benchmark generator's stand-in (sum of 4 uniforms in [-W, W]; default), or -- after
+    // use_discrete_gauss(n, s) -- D_{Z,s} as MatZq::sample_discrete_gauss(.., q, n, 0, s) draws it
+    // (regev.rs:356-363, lpr.rs:342-360); e.g. scheme.randomness().use_discrete_gauss(n, alpha*q)
+    void use_discrete_gauss(uint32_t n, double s) { gauss_n_ = n; gauss_s_ = s; }
+    void use_irwin_hall() { gauss_n_ = 0; }
     std::vector<uint32_t> noise(uint32_t stream, uint64_t count, uint32_t q, uint32_t W) {
         DevBuf<uint32_t> b(*dev_, count);
-        dev_->check(qf_sample_noise_dev(dev_->ctx(), seed_, stream, take(stream, count), count, q, W, b.get()));
+        if (gauss_n_)
+            dev_->check(qf_sample_discrete_gauss_dev(dev_->ctx(), seed_, stream, take(stream, count), count, q, gauss_n_, gauss_s_, b.get()));
+        else
+            dev_->check(qf_sample_noise_dev(dev_->ctx(), seed_, stream, take(stream, count), count, q, W, b.get()));
         return b.download();
     }
     std::vector<uint32_t> bits(uint32_t stream, uint32_t count) {  // MatZ::sample_uniform(m,1,0,2)
@@ -169,6 +177,8 @@ class Randomness {
     const Device *dev_;
     uint64_t seed_;
     uint64_t pos_[16] = {0};
+    uint32_t gauss_n_ = 0;
+    double gauss_s_ = 0.0;
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -17,6 +17,7 @@ void qfo_dot_decode_batch(const uint32_t *s, uint32_t n, uint32_t q, const uint3
 void qfo_sample_bits(uint64_t seed, uint32_t stream, uint64_t first_row, uint64_t rows, uint32_t cols, uint32_t stride_bytes, uint8_t *out);
 void qfo_sample_noise(uint64_t seed, uint32_t stream, uint64_t first, uint64_t count, uint32_t q, uint32_t W, uint32_t *out);
 void qfo_sample_uniform(uint64_t seed, uint32_t stream, uint64_t first, uint64_t count, uint32_t q, uint32_t *out);
+int qfo_sample_discrete_gauss(uint64_t seed, uint32_t stream, uint64_t first, uint64_t count, uint32_t q, uint32_t n, double s, uint32_t *out);
 void qfo_polymul_negacyclic(const uint32_t *a, const uint32_t *b, uint32_t n, uint32_t q, uint32_t *c);
 void qfo_ringlpr_enc_batch(const uint32_t *a, const uint32_t *bpoly, uint32_t n, uint32_t q, const uint32_t *r, const uint32_t *e1,
                            const uint32_t *e2, const uint8_t *mu_bits, uint64_t B, uint32_t *u, uint32_t *v);
@@ -225,6 +226,24 @@ int main() {
             qfo_hash_to_mat_zq(msgs[b].data(), msgs[b].size(), n, 1, q, ref.data());
             CHECK(std::equal(ref.begin(), ref.end(), got.begin() + b * n));
         }
+    });
+    run("discrete_gauss_noise_model", [&] {  // chi = D_{Z,alpha*q} (regev.rs:356-363, lpr.rs:342-360)
+        Randomness rng(dev, 77);
+        rng.use_discrete_gauss(1024, 6711.0);
+        std::vector<uint32_t> got = rng.noise(4, 5000, 1073741789u, 0), ref(5000);
+        CHECK(qfo_sample_discrete_gauss(77, 4, 0, 5000, 1073741789u, 1024, 6711.0, ref.data()) == 0);
+        CHECK(got == ref);
+        LPR l = LPR::new_from_n(dev, 64);
+        l.randomness().use_discrete_gauss(l.n, l.alpha * l.q);
+        auto [pk, sk] = l.gen();
+        for (int64_t msg : {0, 1, 1, 0, 1}) CHECK(l.dec(sk, l.enc(pk, msg)) == msg);
+        Regev r = Regev::default_(dev);
+        r.randomness().use_discrete_gauss(r.n, r.alpha * r.q);
+        auto [rpk, rsk] = r.gen();
+        for (int64_t msg : {1, 0, 1}) CHECK(r.dec(rsk, r.enc(rpk, msg)) == msg);
+        uint32_t dummy = 0;
+        CHECK(qf_sample_discrete_gauss_dev(dev.ctx(), 1, 4, 0, 1, 983, 1, 7.0, &dummy) == QF_ERR_ARG);       // n < 2
+        CHECK(qf_sample_discrete_gauss_dev(dev.ctx(), 1, 4, 0, 1, 983, 1024, 1e7, &dummy) == QF_ERR_NOTSUP); // support > 2^21
     });
     run("rot_minus_kat", [&] {  // utils/rotation_matrix.rs:110-121
         std::vector<int64_t> m = rot_minus({1, 5, -1, 9});
