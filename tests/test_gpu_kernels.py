@@ -334,3 +334,27 @@ def test_discrete_gauss_sampler(ctx, q, n, s):
     keep = exp > 50
     chi2 = (((obs - exp) ** 2) / exp)[keep].sum()
     assert chi2 < keep.sum() + 6 * np.sqrt(2 * keep.sum()), (chi2, keep.sum())
+
+
+def test_replay_fixtures_on_device(ctx):
+    """The fixtures meant for replay through the real reference (tests/golden/replay):
+    the device reproduces every expected value."""
+    import os
+    from crypto_amd.math import MatZ, MatZq, parse_poly
+    path = os.path.join(os.path.dirname(__file__), "golden", "replay", "fixtures.txt")
+    f = dict(l.split("=", 1) for l in open(path).read().splitlines() if "=" in l)
+    u32 = lambda m: np.ascontiguousarray(m.entries.astype(np.uint32))
+    pk, x, c = MatZq.from_str(f["regev_pk"]), MatZ.from_str(f["regev_x"]), MatZq.from_str(f["regev_c"])
+    xb = pack_bits(x.entries[:, 0][None, :].astype(np.uint8), bit_stride(pk.entries.shape[1]))
+    out = ctx.matmul(ctx.key_upload(u32(pk), pk.q), ctx.to_dev_u8(xb), X_BITS, 1, msg=ctx.to_dev_u8(np.array([1], np.uint8)))
+    assert ctx.to_host_u32(out)[0].tolist() == [int(v) for v in c.entries[:, 0]]
+    A, v, d = MatZq.from_str(f["sis_key"]), MatZq.from_str(f["sis_value"]), MatZq.from_str(f["sis_digest"])
+    assert ctx.matvec(ctx.key_upload(u32(A), A.q), u32(v)[:, 0].copy()).tolist() == [int(t) for t in d.entries[:, 0]]
+    pk, r, e, c = (MatZq.from_str(f[k]) for k in ("lpr_pk", "lpr_r", "lpr_e", "lpr_c"))
+    out = ctx.matmul(ctx.key_upload(u32(pk), pk.q), ctx.to_dev_u32(u32(r).T.copy()), X_U32, 1, addend=ctx.to_dev_u32(u32(e).T.copy()),
+                     msg=ctx.to_dev_u8(np.array([1], np.uint8)))
+    assert ctx.to_host_u32(out)[0].tolist() == [int(t) for t in c.entries[:, 0]]
+    n, q = int(f["ring_n"]), int(f["ring_q"])
+    pad = lambda p: np.array([p + [0] * (n - len(p))], np.uint32)
+    a, b, cc = (pad(parse_poly(f[k])) for k in ("ring_a", "ring_b", "ring_c"))
+    assert np.array_equal(ctx.to_host_u32(ctx.ring(n, q).polymul(ctx.to_dev_u32(a), ctx.to_dev_u32(b))), cc)

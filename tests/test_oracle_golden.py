@@ -204,3 +204,32 @@ def test_oracle_discrete_gauss_distribution():
     assert np.array_equal(co.sample_discrete_gauss(SEED, 4, 100, 50, q, n, s), co.sample_discrete_gauss(SEED, 4, 0, 150, q, n, s)[100:])
     with pytest.raises(ValueError):
         co.sample_discrete_gauss(SEED, 4, 0, 1, q, 1024, 1e7)      # support beyond 2^21
+
+
+def _replay():
+    from crypto_amd.math import MatZ, MatZq, parse_poly
+    path = os.path.join(os.path.dirname(__file__), "golden", "replay", "fixtures.txt")
+    f = dict(l.split("=", 1) for l in open(path).read().splitlines() if "=" in l)
+    return f, MatZq, MatZ, parse_poly
+
+
+def test_replay_fixtures_match_the_c_oracle():
+    """tests/golden/replay/fixtures.txt (qfall-math's text formats, for replay through the real reference:
+    tests/golden/make_replay.py) parsed with the host layer's from_str and recomputed by the C oracle."""
+    f, MatZq, MatZ, parse_poly = _replay()
+    pk, x, c = MatZq.from_str(f["regev_pk"]), MatZ.from_str(f["regev_x"]), MatZq.from_str(f["regev_c"])
+    q = pk.q
+    y = co.matvec(pk.entries.astype(np.uint32), x.entries[:, 0].astype(np.uint32), q).astype(np.int64)
+    y[-1] = (y[-1] + q // 2) % q
+    assert y.tolist() == [int(v) for v in c.entries[:, 0]]
+    A, v, d = MatZq.from_str(f["sis_key"]), MatZq.from_str(f["sis_value"]), MatZq.from_str(f["sis_digest"])
+    assert co.matvec(A.entries.astype(np.uint32), v.entries[:, 0].astype(np.uint32), A.q).tolist() == [int(t) for t in d.entries[:, 0]]
+    pk, r, e, c = (MatZq.from_str(f[k]) for k in ("lpr_pk", "lpr_r", "lpr_e", "lpr_c"))
+    q = pk.q
+    y = (co.matvec(pk.entries.astype(np.uint32), r.entries[:, 0].astype(np.uint32), q).astype(np.int64) + e.entries[:, 0].astype(np.int64)) % q
+    y[-1] = (y[-1] + q // 2) % q
+    assert y.tolist() == [int(t) for t in c.entries[:, 0]]
+    n, q = int(f["ring_n"]), int(f["ring_q"])
+    pad = lambda p: np.array([p + [0] * (n - len(p))], np.uint32)
+    a, b, cc = (pad(parse_poly(f[k])) for k in ("ring_a", "ring_b", "ring_c"))
+    assert np.array_equal(co.polymul_batch(a, b, q), cc)
