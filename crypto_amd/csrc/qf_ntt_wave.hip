@@ -223,6 +223,10 @@ __global__ __launch_bounds__(WV_THREADS) void qf_ring_wave_kernel(QfRingArgs a) 
     };
 
     for (uint64_t item = (uint64_t)blockIdx.x * WV_WAVES + wave; item < a.B; item += (uint64_t)gridDim.x * WV_WAVES) {
+        // RLPR_ENC: a compiler barrier per item keeps hipcc from holding every stage's twiddles live
+        // across items (it did, at 256 VGPRs + AGPR copies and one wave per SIMD); re-read from LDS per
+        // item the kernel fits two waves per SIMD without scratch
+        if constexpr (MODE == MODE_RLPR_ENC) asm volatile("" ::: "memory");
         if constexpr (MODE == MODE_POLYMUL) {
             uint32_t xa[R], xb[R];
             load_nat(xa, a.in0 + item * N);
