@@ -4,3 +4,4 @@ from .regev import Regev  # noqa: F401
 from .dual_regev import DualRegev  # noqa: F401
 from .lpr import LPR  # noqa: F401
 from .ring_lpr import RingLPR  # noqa: F401
+from .regev_discrete_gauss import DualRegevWithDiscreteGaussianRegularity, RegevWithDiscreteGaussianRegularity  # noqa: F401

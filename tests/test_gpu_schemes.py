@@ -256,3 +256,52 @@ def test_lpr_noise_digits_follow_the_model(ctx):
     assert g.noise_digits in (2, 3)
     with pytest.raises(ValueError):
         LPR.default(ctx=ctx, noise_model="binomial")
+
+
+from crypto_amd.construction.pk_encryption import (DualRegevWithDiscreteGaussianRegularity as DualRegevDG,
+                                                    RegevWithDiscreteGaussianRegularity as RegevDG)
+
+
+@pytest.mark.parametrize("make", [RegevDG.default, lambda **k: RegevDG.new_from_n(3, **k), lambda **k: RegevDG.new_from_n(10, **k),
+                                  RegevDG.secure128, DualRegevDG.default, lambda **k: DualRegevDG.new_from_n(5, **k),
+                                  lambda **k: DualRegevDG.new_from_n(10, **k), DualRegevDG.secure128])
+def test_gaussian_regularity_variants_cycle(ctx, make):
+    """regev_discrete_gauss.rs / dual_regev_discrete_gauss.rs test_encryption modules (cycle_zero_*, cycle_one_*):
+    gen -> enc -> dec == msg, single messages, multi-bit and a batch; the batch is also checked against the oracle."""
+    s = make(ctx=ctx)
+    pk, sk = s.gen()
+    for msg in (0, 1, 1, 0):
+        assert s.dec(sk, s.enc(pk, msg)) == msg
+    assert s.dec_multiple_bits(sk, s.enc_multiple_bits(pk, 13)) == 13
+    B = 200
+    msgs = (np.arange(B) * 7 % 3 == 0).astype(np.int64)
+    C = s.enc_batch(pk, msgs)
+    assert s.dec_batch(sk, C).tolist() == msgs.tolist()
+    # parity of the batch with the oracle on the same seeded draws
+    if isinstance(s, RegevDG):
+        K = np.vstack([pk[0].entries, pk[1].entries.T]).astype(np.uint32)
+        pos = s.rng.pos[3] - B * s.m
+        e = co.sample_discrete_gauss(s.rng.seed, 3, pos, B * s.m, s.q, s.n, float(s.r)).reshape(B, s.m)
+        ref = co.matmul_batch(K, s.q, e, co.X_U32, B, msg=msgs.astype(np.uint8))
+    else:
+        K = np.ascontiguousarray(np.hstack([pk[0].entries, pk[1].entries]).astype(np.uint32).T)
+        S = co.sample_uniform(s.rng.seed, 3, s.rng.pos[3] - B * s.n, B * s.n, s.q).reshape(B, s.n)
+        X = co.sample_discrete_gauss(s.rng.seed, 4, s.rng.pos[4] - B * (s.m + 1), B * (s.m + 1), s.q, s.n,
+                                     float(s.alpha * s.q)).reshape(B, s.m + 1)
+        ref = co.matmul_batch(K, s.q, S, co.X_U32, B, addend=X, msg=msgs.astype(np.uint8))
+    assert np.array_equal(ctx.to_host_u32(C), ref)
+
+
+def test_gaussian_regularity_parameter_rules():
+    """regev_discrete_gauss.rs test_pp_generation: new_from_n yields correct + secure sets, n <= 1 panics,
+    the fixed sets pass their own checks."""
+    for cls in (RegevDG, DualRegevDG):
+        for n in (2, 3, 5, 8, 12, 25):
+            p = cls.new_from_n(n, ctx=object())
+            p.check_correctness(); p.check_security()
+            assert p.m >= 2 * (n + 1) * np.log10(p.q)
+        cls.default(ctx=object()).check_correctness()
+        cls.secure128(ctx=object()).check_correctness()
+        cls.secure128(ctx=object()).check_security()
+        with pytest.raises(ValueError):
+            cls.new_from_n(1, ctx=object())
