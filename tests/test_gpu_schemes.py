@@ -305,3 +305,40 @@ def test_gaussian_regularity_parameter_rules():
         cls.secure128(ctx=object()).check_security()
         with pytest.raises(ValueError):
             cls.new_from_n(1, ctx=object())
+
+
+def test_classical_gpv_psf_and_fdh_verify(ctx):
+    """primitive/psf/gpv.rs:189-223 and signature/fdh.rs:115-123 with fdh/gpv.rs:40-60: f_a = A*sigma,
+    check_domain, vfy = in domain && f_a == H(m).  The trapdoor sampler is out of scope, so A's last
+    column is solved for so that a chosen short sigma (last entry 1) IS a preimage of H(m)."""
+    from crypto_amd.construction.hash.sha256 import hash_to_mat_zq_sha256
+    from crypto_amd.math import MatZ
+    from crypto_amd.primitive.psf import PSFGPV, GadgetParameters
+    n, q = 4, 64
+    s = ((n * 6) ** 0.5 + 1) * 2 * np.log2(2 * n * 6)            # the reference test's choice (fdh/gpv.rs test)
+    fdh = FDH.init_gpv(n, q, s, ctx=ctx)
+    psf = fdh.psf
+    assert isinstance(psf, PSFGPV) and psf.gp.k == 6 and psf.gp.m_bar == 4 * 6 + 4 and psf.m == 52
+    rng = np.random.default_rng(5)
+    msgs = ["Hello World!", "qfall", "", "x" * 100]
+    sigmas, A = [], rng.integers(0, q, (n, psf.m)).astype(np.int64)
+    sig = rng.integers(-3, 4, psf.m).astype(np.int64)
+    sig[-1] = 1
+    u = hash_to_mat_zq_sha256(msgs[0], n, 1, q).entries[:, 0].astype(np.int64)
+    A[:, -1] = (u - A[:, :-1] @ sig[:-1]) % q
+    Aq = MatZq(A, q)
+    good = MatZ(sig[:, None])
+    assert psf.check_domain(good)
+    t = psf.f_a(Aq, good)
+    assert t.entries[:, 0].tolist() == po.matvec(A.tolist(), [int(v) % q for v in sig], q) == u.tolist()
+    assert fdh.vfy(msgs[0], good, Aq)
+    assert not fdh.vfy(msgs[1], good, Aq)                               # other message
+    big = MatZ((sig * 1000)[:, None])
+    assert not psf.check_domain(big) and not fdh.vfy(msgs[0], big, Aq)  # out of domain
+    assert not psf.check_domain(MatZ(sig[None, :])) and not psf.check_domain(MatZ(sig[:-1, None]))
+    with pytest.raises(AssertionError):
+        psf.f_a(Aq, big)
+    res = fdh.vfy_batch(msgs, [good, good, big, good], Aq)
+    assert res == [True, False, False, False]
+    with pytest.raises(NotImplementedError):
+        psf.samp_p(None, None, None)
