@@ -496,6 +496,7 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a, const uint32_t
                 for (int l = 0; l < LA; l++)
                     x += (int64_t)__shfl(acc[i][j][0][r], (int)(lane - l0 + l), 64) * (int64_t)a.cs[l];
                 if (!owner || mrow >= a.B) continue;
+                if (a.addend) x += (int64_t)a.addend[mrow * a.rows + krow];
                 if (krow == lastrow && ((msgmask[i] >> ((r & 3) + 8 * (r >> 2) + 4 * h)) & 1)) x += (int64_t)a.mod.qhalf;
                 a.out[mrow * a.rows + krow] = qf_red_i64(x, a.mod);
             }

@@ -358,3 +358,18 @@ def test_replay_fixtures_on_device(ctx):
     pad = lambda p: np.array([p + [0] * (n - len(p))], np.uint32)
     a, b, cc = (pad(parse_poly(f[k])) for k in ("ring_a", "ring_b", "ring_c"))
     assert np.array_equal(ctx.to_host_u32(ctx.ring(n, q).polymul(ctx.to_dev_u32(a), ctx.to_dev_u32(b))), cc)
+
+
+@pytest.mark.parametrize("rows,cols,q,B", [(33, 31, 12289, 257), (257, 17, 16777213, 300), (4, 1012, 65521, 40), (296, 253, 16777213, 65)])
+def test_matmul_bits_with_addend_on_packed_remainder(ctx, rows, cols, q, B):
+    """Bit operand + addend (+ message) on keys with a packed remainder block: the remainder rows take the
+    addend too (found by tools/soak_gemm.py: the packed epilogue used to drop it)."""
+    A = co.sample_uniform(SEED, 1, 0, rows * cols, q).reshape(rows, cols)
+    xb = co.sample_bits(SEED, 3, 0, B, cols, bit_stride(cols))
+    E = co.sample_uniform(SEED, 4, 0, B * rows, q).reshape(B, rows)
+    msg = co.sample_uniform(SEED, 5, 0, B, 2).astype(np.uint8)
+    key = ctx.key_upload(A, q)
+    out = ctx.matmul(key, ctx.to_dev_u8(xb), X_BITS, B, addend=ctx.to_dev_u32(E), msg=ctx.to_dev_u8(msg))
+    assert np.array_equal(ctx.to_host_u32(out), co.matmul_batch(A, q, xb, co.X_BITS, B, addend=E, msg=msg))
+    out = ctx.matmul(key, ctx.to_dev_u8(xb), X_BITS, B, addend=ctx.to_dev_u32(E))
+    assert np.array_equal(ctx.to_host_u32(out), co.matmul_batch(A, q, xb, co.X_BITS, B, addend=E))

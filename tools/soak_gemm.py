@@ -1,0 +1,50 @@
+"""Diagnostic soak: random shapes / moduli / digit promises / batch sizes for the mod-q GEMM paths against the C
+oracle (beyond the seeded cases of tests/test_gpu_random_shapes.py).  usage: python tools/soak_gemm.py [cases] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from oracle import coracle as co
+from crypto_amd.device import Context, X_BITS, X_U32, X_I32, bit_stride
+
+PRIMES = [7, 16, 251, 257, 12289, 65521, 65537, 8380417, 16777213, 16777259, 1073741789, 2147483629]
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 11)
+ctx = Context(0)
+SEED = 99
+bad = 0
+t0 = time.time()
+for c in range(ncases):
+    q = int(rng.choice(PRIMES))
+    rows = int(rng.choice([rng.integers(1, 40), rng.integers(60, 140), rng.integers(250, 300)]))
+    cols = int(rng.choice([rng.integers(1, 40), rng.integers(100, 140), rng.integers(250, 262), rng.integers(1000, 1100)]))
+    B = int(rng.choice([1, 33, 257, 300, 2049, 8193 + int(rng.integers(0, 700))]))
+    kind = int(rng.integers(0, 4))
+    A = co.sample_uniform(SEED, 1, c, rows * cols, q).reshape(rows, cols)
+    key = ctx.key_upload(A, q)
+    msg = co.sample_uniform(SEED, 5, c, B, 2).astype(np.uint8) if rng.integers(0, 2) else None
+    E = co.sample_uniform(SEED, 4, c, B * rows, q).reshape(B, rows) if rng.integers(0, 2) else None
+    dm = None if msg is None else ctx.to_dev_u8(msg)
+    de = None if E is None else ctx.to_dev_u32(E)
+    if kind == 0:
+        xb = co.sample_bits(SEED, 3, c, B, cols, bit_stride(cols))
+        out = ctx.matmul(key, ctx.to_dev_u8(xb), X_BITS, B, addend=de, msg=dm)
+        ref = co.matmul_batch(A, q, xb, co.X_BITS, B, addend=E, msg=msg, mt=True)
+    elif kind == 1:
+        X = co.sample_uniform(SEED, 6, c, B * cols, q).reshape(B, cols)
+        out = ctx.matmul(key, ctx.to_dev_u32(X), X_U32, B, addend=de, msg=dm)
+        ref = co.matmul_batch(A, q, X, co.X_U32, B, addend=E, msg=msg, mt=True)
+    elif kind == 2:
+        W = int(rng.choice([1, 30, 3000, 100000]))
+        X = co.sample_noise(SEED, 3, c, B * cols, q, W).reshape(B, cols)
+        out = ctx.matmul(key, ctx.to_dev_u32(X), X_U32, B, addend=de, msg=dm, x_digits=int(rng.integers(1, 4)))
+        ref = co.matmul_batch(A, q, X, co.X_U32, B, addend=E, msg=msg, mt=True)
+    else:
+        X = rng.integers(-5000, 5001, (B, cols)).astype(np.int32)
+        out = ctx.matmul(key, ctx.to_dev_i32(X), X_I32, B, addend=de, msg=dm, x_digits=2)
+        ref = co.matmul_batch(A, q, (X.astype(np.int64) % q).astype(np.uint32), co.X_U32, B, addend=E, msg=msg, mt=True)
+    ok = np.array_equal(ctx.to_host_u32(out), ref)
+    bad += not ok
+    print("case %3d kind %d rows %3d cols %4d q %10d B %5d addend %d msg %d %s" % (c, kind, rows, cols, q, B, E is not None, msg is not None, "ok" if ok else "MISMATCH"), flush=True)
+    key.close()
+print("%d cases, %d mismatches, %.1f s" % (ncases, bad, time.time() - t0))
+sys.exit(1 if bad else 0)
