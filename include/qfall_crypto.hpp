@@ -596,6 +596,221 @@ class RingLPR : public PKEncryptionScheme<RingLPR, RingPair, PolynomialRingZq, R
 };
 
 // ---------------------------------------------------------------------------------------------
+// RegevWithDiscreteGaussianRegularity / DualRegevWithDiscreteGaussianRegularity
+// (regev_discrete_gauss.rs, dual_regev_discrete_gauss.rs): the same kernels as Regev / DualRegev;
+// chi = D_{Z,alpha*q} and SampleD over Z^m (= m independent D_{Z,r} draws) come from
+// qf_sample_discrete_gauss_dev.
+// ---------------------------------------------------------------------------------------------
+struct GaussRegularityParams {
+    uint32_t n, m, q;
+    double r, alpha;
+    // regev_discrete_gauss.rs:161-199: q prime in [n^p/2, n^p], m = ceil(2(n+1) lg q) (lg = log10 there),
+    // r = log2 m, alpha = 1/(sqrt(m) log2^2 m); "random prime" -> largest prime, next smaller while checks fail
+    static GaussRegularityParams from_n(uint32_t n) {
+        if (n <= 1) throw Panic("n must be chosen bigger than 1.");
+        const int power = n == 2 ? 9 : n == 3 ? 8 : n <= 5 ? 7 : n <= 8 ? 6 : n <= 12 ? 5 : n <= 30 ? 4 : 3;
+        const uint64_t ub = ipow(n, power), lb = (ub + 1) / 2;
+        uint64_t upper = ub;
+        for (;;) {
+            const uint64_t qq = largest_prime_at_most(upper, lb);
+            GaussRegularityParams p;
+            p.n = n; p.q = (uint32_t)qq;
+            p.m = (uint32_t)std::ceil(2.0 * (n + 1) * std::log10((double)qq));
+            p.r = std::log2((double)p.m);
+            p.alpha = 1.0 / (std::sqrt((double)p.m) * std::pow(std::log2((double)p.m), 2));
+            try { p.check_correctness(); p.check_security(); return p; } catch (const MathError &) { upper = qq - 1; }
+        }
+    }
+    void check_correctness() const {  // regev_discrete_gauss.rs:222-246
+        if (n <= 1) throw MathError("n must be chosen bigger than 1.");
+        if (q < 5 * r * m) throw MathError("Correctness is not guaranteed as q < 5rm, but q >= 5rm is required.");
+        if (alpha > 1 / (r * std::sqrt((double)m) * std::sqrt(std::log2((double)n)))) throw MathError("Correctness is not guaranteed as alpha > 1/(r*sqrt(m)*w(sqrt(log n))");
+    }
+    void check_security() const {  // regev_discrete_gauss.rs:270-297
+        if (q * alpha < n) throw MathError("Security is not guaranteed as q * alpha < n, but q * alpha >= n is required.");
+        if (m < 2.0 * (n + 1) * std::log10((double)q)) throw MathError("Security is not guaranteed as m < 2(n + 1) lg (q)");
+        if (r < std::sqrt(std::log2((double)m))) throw MathError("Security is not guaranteed as r < sqrt( log m )");
+    }
+};
+
+struct GaussCipher { MatZq vec; uint32_t c = 0; };       // (u, c) resp. (p, c): (MatZq, Zq)
+struct GaussPublicKey { MatZq a; MatZq v; };             // (A, p) resp. (A, u)
+
+class RegevWithDiscreteGaussianRegularity
+    : public PKEncryptionScheme<RegevWithDiscreteGaussianRegularity, GaussPublicKey, MatZq, GaussCipher> {
+  public:
+    GaussRegularityParams pp;
+    RegevWithDiscreteGaussianRegularity(const Device &d, uint32_t n, uint32_t m, uint32_t q, double r, double alpha, uint64_t seed = MASTER_SEED)
+        : pp{n, m, q, r, alpha}, dev(&d), rng(d, seed) { if (q <= 1) throw Panic("modulus must be > 1"); }
+    static RegevWithDiscreteGaussianRegularity default_(const Device &d) { return {d, 2, 16, 443, 4, 1.0 / 64}; }             // :329-338
+    static RegevWithDiscreteGaussianRegularity secure128(const Device &d) { return {d, 350, 5248, 29892991, 12.357, 0.00009}; }  // :312-314
+    static RegevWithDiscreteGaussianRegularity new_from_n(const Device &d, uint32_t n) {
+        GaussRegularityParams p = GaussRegularityParams::from_n(n);
+        return {d, p.n, p.m, p.q, p.r, p.alpha};
+    }
+    // regev_discrete_gauss.rs:369-393: s <- Z_q^n, A <- Z_q^{n x m}, x <- chi^m, p = A^t s + x
+    std::pair<GaussPublicKey, MatZq> gen() {
+        MatZq sk(pp.n, 1, pp.q), A(pp.n, pp.m, pp.q), p(pp.m, 1, pp.q);
+        sk.e = rng.uniform(2, pp.n, pp.q);
+        A.e = rng.uniform(1, (uint64_t)pp.n * pp.m, pp.q);
+        std::vector<uint32_t> x = gauss(4, pp.m, pp.alpha * pp.q);
+        { DevKey ka(*dev, A); dev->check(qf_vecmat_modq_host(dev->ctx(), ka.get(), sk.e.data(), p.e.data())); }
+        for (uint32_t j = 0; j < pp.m; j++) p.e[j] = (uint32_t)(((uint64_t)p.e[j] + x[j]) % pp.q);
+        return {GaussPublicKey{A, p}, sk};
+    }
+    // regev_discrete_gauss.rs:413-430: e <- SampleD(Z^m, r); u = A e, c = p^t e + msg floor(q/2)
+    GaussCipher enc(const GaussPublicKey &pk, int64_t message) {
+        MatZq K = stacked(pk);
+        std::vector<uint32_t> e = gauss(3, pp.m, pp.r), y(pp.n + 1);
+        DevKey k(*dev, K);
+        dev->check(qf_matvec_modq_host(dev->ctx(), k.get(), e.data(), y.data()));
+        GaussCipher out{MatZq(pp.n, 1, pp.q), (uint32_t)(((uint64_t)y[pp.n] + (uint64_t)message_bit(message) * (pp.q / 2)) % pp.q)};
+        std::copy(y.begin(), y.begin() + pp.n, out.vec.e.begin());
+        return out;
+    }
+    // regev_discrete_gauss.rs:451-462: c - <s, u>
+    int64_t dec(const MatZq &sk, const GaussCipher &cipher) {
+        if (sk.rows != pp.n || cipher.vec.rows != pp.n) throw Panic("mismatching matrix dimensions");
+        std::vector<uint32_t> w(pp.n), row(cipher.vec.e);
+        for (uint32_t i = 0; i < pp.n; i++) w[i] = (pp.q - sk.e[i] % pp.q) % pp.q;
+        row.push_back(cipher.c % pp.q);
+        DevBuf<uint32_t> dc(*dev, row);
+        return decode_batch(*dev, w, pp.q, dc.get(), 1)[0];
+    }
+    // B encryptions on kernel (a) with E = B x m SampleD rows (device-drawn): rows (u_b ; c_b)
+    DevBuf<uint32_t> enc_batch(const GaussPublicKey &pk, const std::vector<uint8_t> &msg_bits) {
+        MatZq K = stacked(pk);
+        const uint64_t B = msg_bits.size();
+        DevBuf<uint32_t> E(*dev, B * pp.m), out(*dev, B * (pp.n + 1));
+        dev->check(qf_sample_discrete_gauss_dev(dev->ctx(), rng.seed(), 3, rng.take(3, B * pp.m), B * pp.m, pp.q, pp.n, pp.r, E.get()));
+        DevKey k(*dev, K);
+        DevBuf<uint8_t> dm(*dev, msg_bits);
+        dev->check(qf_matmul_modq_dev(dev->ctx(), k.get(), E.get(), QF_X_U32, (size_t)pp.m * 4, 0, B, nullptr, dm.get(), out.get()));
+        return out;
+    }
+    std::vector<uint8_t> dec_batch(const MatZq &sk, const uint32_t *C_dev, uint64_t B) {
+        std::vector<uint32_t> w(pp.n);
+        for (uint32_t i = 0; i < pp.n; i++) w[i] = (pp.q - sk.e[i] % pp.q) % pp.q;
+        return decode_batch(*dev, w, pp.q, C_dev, B);
+    }
+    Randomness &randomness() { return rng; }
+
+  private:
+    std::vector<uint32_t> gauss(uint32_t stream, uint64_t count, double s) {
+        DevBuf<uint32_t> b(*dev, count);
+        dev->check(qf_sample_discrete_gauss_dev(dev->ctx(), rng.seed(), stream, rng.take(stream, count), count, pp.q, pp.n, s, b.get()));
+        return b.download();
+    }
+    MatZq stacked(const GaussPublicKey &pk) const {   // K = [A ; p^t]
+        if (pk.a.q != pp.q || pk.v.q != pp.q) throw Panic("mismatching modulus between scheme and key");
+        if (pk.a.rows != pp.n || pk.a.cols != pp.m || pk.v.rows != pp.m || pk.v.cols != 1) throw Panic("mismatching matrix dimensions");
+        MatZq K(pp.n + 1, pp.m, pp.q);
+        std::copy(pk.a.e.begin(), pk.a.e.end(), K.e.begin());
+        std::copy(pk.v.e.begin(), pk.v.e.end(), K.e.begin() + (size_t)pp.n * pp.m);
+        return K;
+    }
+    const Device *dev;
+    Randomness rng;
+};
+
+class DualRegevWithDiscreteGaussianRegularity
+    : public PKEncryptionScheme<DualRegevWithDiscreteGaussianRegularity, GaussPublicKey, MatZq, GaussCipher> {
+  public:
+    GaussRegularityParams pp;
+    DualRegevWithDiscreteGaussianRegularity(const Device &d, uint32_t n, uint32_t m, uint32_t q, double r, double alpha, uint64_t seed = MASTER_SEED)
+        : pp{n, m, q, r, alpha}, dev(&d), rng(d, seed) { if (q <= 1) throw Panic("modulus must be > 1"); }
+    static DualRegevWithDiscreteGaussianRegularity default_(const Device &d) { return {d, 2, 16, 443, 4, 1.0 / 64}; }
+    static DualRegevWithDiscreteGaussianRegularity secure128(const Device &d) { return {d, 350, 5248, 29892991, 12.357, 0.00009}; }
+    static DualRegevWithDiscreteGaussianRegularity new_from_n(const Device &d, uint32_t n) {
+        GaussRegularityParams p = GaussRegularityParams::from_n(n);
+        return {d, p.n, p.m, p.q, p.r, p.alpha};
+    }
+    // dual_regev_discrete_gauss.rs:369-383: A uniform, e <- SampleD(Z^m, r), u = A e; sk = e
+    std::pair<GaussPublicKey, MatZq> gen() {
+        MatZq A(pp.n, pp.m, pp.q), u(pp.n, 1, pp.q), sk(pp.m, 1, pp.q);
+        A.e = rng.uniform(1, (uint64_t)pp.n * pp.m, pp.q);
+        sk.e = gauss(2, pp.m, pp.r);
+        { DevKey ka(*dev, A); dev->check(qf_matvec_modq_host(dev->ctx(), ka.get(), sk.e.data(), u.e.data())); }
+        return {GaussPublicKey{A, u}, sk};
+    }
+    // dual_regev_discrete_gauss.rs:404-431: p = A^t s + x, c = u^t s + x' + msg floor(q/2)
+    GaussCipher enc(const GaussPublicKey &pk, int64_t message) {
+        MatZq K = joined(pk);
+        std::vector<uint32_t> s = rng.uniform(3, pp.n, pp.q), x = gauss(4, pp.m + 1, pp.alpha * pp.q), y(pp.m + 1);
+        DevKey k(*dev, K);
+        dev->check(qf_vecmat_modq_host(dev->ctx(), k.get(), s.data(), y.data()));
+        for (uint32_t j = 0; j <= pp.m; j++) y[j] = (uint32_t)(((uint64_t)y[j] + x[j]) % pp.q);
+        GaussCipher out{MatZq(pp.m, 1, pp.q), (uint32_t)(((uint64_t)y[pp.m] + (uint64_t)message_bit(message) * (pp.q / 2)) % pp.q)};
+        std::copy(y.begin(), y.begin() + pp.m, out.vec.e.begin());
+        return out;
+    }
+    // dual_regev_discrete_gauss.rs:455-466: c - <e, p>
+    int64_t dec(const MatZq &sk, const GaussCipher &cipher) {
+        if (sk.rows != pp.m || cipher.vec.rows != pp.m) throw Panic("mismatching matrix dimensions");
+        std::vector<uint32_t> w(pp.m), row(cipher.vec.e);
+        for (uint32_t i = 0; i < pp.m; i++) w[i] = (pp.q - sk.e[i] % pp.q) % pp.q;
+        row.push_back(cipher.c % pp.q);
+        DevBuf<uint32_t> dc(*dev, row);
+        return decode_batch(*dev, w, pp.q, dc.get(), 1)[0];
+    }
+    Randomness &randomness() { return rng; }
+
+  private:
+    std::vector<uint32_t> gauss(uint32_t stream, uint64_t count, double s) {
+        DevBuf<uint32_t> b(*dev, count);
+        dev->check(qf_sample_discrete_gauss_dev(dev->ctx(), rng.seed(), stream, rng.take(stream, count), count, pp.q, pp.n, s, b.get()));
+        return b.download();
+    }
+    MatZq joined(const GaussPublicKey &pk) const {   // K = [A | u]
+        if (pk.a.q != pp.q || pk.v.q != pp.q) throw Panic("mismatching modulus between scheme and key");
+        if (pk.a.rows != pp.n || pk.a.cols != pp.m || pk.v.rows != pp.n || pk.v.cols != 1) throw Panic("mismatching matrix dimensions");
+        MatZq K(pp.n, pp.m + 1, pp.q);
+        for (uint32_t i = 0; i < pp.n; i++) {
+            std::copy(pk.a.e.begin() + (size_t)i * pp.m, pk.a.e.begin() + (size_t)(i + 1) * pp.m, K.e.begin() + (size_t)i * (pp.m + 1));
+            K.e[(size_t)i * (pp.m + 1) + pp.m] = pk.v.e[i];
+        }
+        return K;
+    }
+    const Device *dev;
+    Randomness rng;
+};
+
+// ---------------------------------------------------------------------------------------------
+// classical GPV PSF, verify half (primitive/psf/gpv.rs:189-223): f_a = A*sigma, check_domain
+// ---------------------------------------------------------------------------------------------
+class PSFGPV {
+  public:
+    uint32_t n, q, k, m_bar;
+    double s;
+    PSFGPV(const Device &d, uint32_t n_, uint32_t q_, double s_) : n(n_), q(q_), s(s_), dev(&d) {   // gadget_parameters.rs:86-108
+        if (n < 1) throw Panic("n must be at least 1");
+        k = log2_ceil(q);
+        const uint32_t ln = log2_ceil(n);
+        m_bar = n * k + ln * ln;
+    }
+    uint32_t m() const { return n * k + m_bar; }
+    bool check_domain(const MatZ &sigma) const {   // gpv.rs:218-223 (exact: the norm in 128-bit integers)
+        if (sigma.cols != 1 || sigma.rows != m() || sigma.e.size() != m()) return false;
+        unsigned __int128 norm = 0;
+        for (int64_t v : sigma.e) norm += (unsigned __int128)((__int128)v * v);
+        return (long double)norm <= (long double)s * s * m();
+    }
+    MatZq f_a(const MatZq &a, const MatZ &sigma) const {   // gpv.rs:189-192
+        if (!check_domain(sigma)) throw Panic("sigma is not in the domain");
+        if (a.q != q || a.rows != n || a.cols != m()) throw Panic("mismatching matrix dimensions");
+        std::vector<uint32_t> x(m());
+        for (uint32_t i = 0; i < m(); i++) x[i] = (uint32_t)(((sigma.e[i] % (int64_t)q) + q) % q);
+        MatZq out(n, 1, q);
+        DevKey key(*dev, a);
+        dev->check(qf_matvec_modq_host(dev->ctx(), key.get(), x.data(), out.e.data()));
+        return out;
+    }
+
+  private:
+    const Device *dev;
+};
+
+// ---------------------------------------------------------------------------------------------
 // SISHash (hash/sis.rs)
 // ---------------------------------------------------------------------------------------------
 class SISHash {

@@ -245,6 +245,59 @@ int main() {
         CHECK(qf_sample_discrete_gauss_dev(dev.ctx(), 1, 4, 0, 1, 983, 1, 7.0, &dummy) == QF_ERR_ARG);       // n < 2
         CHECK(qf_sample_discrete_gauss_dev(dev.ctx(), 1, 4, 0, 1, 983, 1024, 1e7, &dummy) == QF_ERR_NOTSUP); // support > 2^21
     });
+    run("gaussian_regularity_variants", [&] {  // regev_discrete_gauss.rs / dual_regev_discrete_gauss.rs cycle_* tests
+        for (int which = 0; which < 3; which++) {
+            RegevWithDiscreteGaussianRegularity r = which == 0 ? RegevWithDiscreteGaussianRegularity::default_(dev)
+                                                   : which == 1 ? RegevWithDiscreteGaussianRegularity::new_from_n(dev, 10)
+                                                                : RegevWithDiscreteGaussianRegularity::secure128(dev);
+            if (which) { r.pp.check_correctness(); r.pp.check_security(); }
+            auto [pk, sk] = r.gen();
+            CHECK(pk.a.rows == r.pp.n && pk.a.cols == r.pp.m && pk.v.rows == r.pp.m && sk.rows == r.pp.n);
+            for (int64_t msg : {0, 1, 1, 0}) CHECK(r.dec(sk, r.enc(pk, msg)) == msg);
+            CHECK(r.dec_multiple_bits(sk, r.enc_multiple_bits(pk, 13)) == 13);
+            std::vector<uint8_t> msg(100);
+            for (size_t i = 0; i < msg.size(); i++) msg[i] = (uint8_t)((i * 7 % 3) == 0);
+            const uint64_t pos = r.randomness().take(3, 0);
+            DevBuf<uint32_t> C = r.enc_batch(pk, msg);
+            CHECK(r.dec_batch(sk, C.get(), msg.size()) == msg);
+            // the batch against the oracle on the same seeded SampleD draws
+            std::vector<uint32_t> E(msg.size() * r.pp.m), K((size_t)(r.pp.n + 1) * r.pp.m), ref(msg.size() * (r.pp.n + 1));
+            CHECK(qfo_sample_discrete_gauss(r.randomness().seed(), 3, pos, E.size(), r.pp.q, r.pp.n, r.pp.r, E.data()) == 0);
+            std::copy(pk.a.e.begin(), pk.a.e.end(), K.begin());
+            std::copy(pk.v.e.begin(), pk.v.e.end(), K.begin() + (size_t)r.pp.n * r.pp.m);
+            qfo_matmul_batch(K.data(), r.pp.n + 1, r.pp.m, r.pp.q, E.data(), 1, (size_t)r.pp.m * 4, msg.size(), nullptr, msg.data(), ref.data());
+            CHECK(C.download() == ref);
+        }
+        for (int which = 0; which < 2; which++) {
+            DualRegevWithDiscreteGaussianRegularity d2 = which == 0 ? DualRegevWithDiscreteGaussianRegularity::default_(dev)
+                                                                    : DualRegevWithDiscreteGaussianRegularity::new_from_n(dev, 10);
+            auto [pk, sk] = d2.gen();
+            CHECK(pk.v.rows == d2.pp.n && sk.rows == d2.pp.m);
+            for (int64_t msg : {1, 0, 0, 1}) CHECK(d2.dec(sk, d2.enc(pk, msg)) == msg);
+        }
+        CHECK(throws<Panic>([&] { RegevWithDiscreteGaussianRegularity::new_from_n(dev, 1); }));
+        CHECK(throws<MathError>([&] { GaussRegularityParams{2, 16, 443, 4, 0.9}.check_correctness(); }));
+    });
+    run("classical_gpv_psf", [&] {  // primitive/psf/gpv.rs:189-223
+        PSFGPV psf(dev, 4, 64, 60.0);
+        CHECK(psf.k == 6 && psf.m_bar == 28 && psf.m() == 52);
+        Randomness rng(dev, 5);
+        MatZq A(4, psf.m(), 64);
+        A.e = rng.uniform(1, (uint64_t)4 * psf.m(), 64);
+        MatZ sig; sig.rows = psf.m(); sig.cols = 1; sig.e.resize(psf.m());
+        for (uint32_t i = 0; i < psf.m(); i++) sig.e[i] = (int64_t)(i % 7) - 3;
+        CHECK(psf.check_domain(sig));
+        MatZq t = psf.f_a(A, sig);
+        std::vector<uint32_t> x(psf.m()), ref(4);
+        for (uint32_t i = 0; i < psf.m(); i++) x[i] = (uint32_t)(((sig.e[i] % 64) + 64) % 64);
+        qfo_matvec(A.e.data(), 4, psf.m(), 64, x.data(), ref.data());
+        CHECK(t.e == ref);
+        MatZ big = sig; big.e[3] = 100000;
+        CHECK(!psf.check_domain(big));
+        CHECK(throws<Panic>([&] { psf.f_a(A, big); }));
+        MatZ shortv = sig; shortv.rows--; shortv.e.pop_back();
+        CHECK(!psf.check_domain(shortv));
+    });
     run("rot_minus_kat", [&] {  // utils/rotation_matrix.rs:110-121
         std::vector<int64_t> m = rot_minus({1, 5, -1, 9});
         std::vector<int64_t> want = {1, -9, 1, -5, 5, 1, -9, 1, -1, 5, 1, -9, 9, -1, 5, 1};
