@@ -45,7 +45,12 @@ class _GaussianRegularityBase(MatrixSchemeMixin, GenericMultiBitEncryption):
             raise ValueError("n must be chosen bigger than 1.")
         upper = None
         while True:
-            m, q, r, alpha = cls.gen_new_public_parameters(n, upper)
+            try:
+                m, q, r, alpha = cls.gen_new_public_parameters(n, upper)
+            except MathError:
+                # n = 31..36: no prime of [n^3/2, n^3] satisfies q*alpha >= n -- the reference's loop
+                # (regev_discrete_gauss.rs:144-156) would sample forever; report it instead
+                raise MathError(f"no prime q in the range new_from_n({n}) draws from passes check_correctness and check_security")
             out = cls(n, m, q, r, alpha, **kw)
             try:
                 out.check_correctness()

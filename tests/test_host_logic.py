@@ -144,3 +144,15 @@ def test_bit_packing_helpers():
     assert p.shape == (5, bit_stride(867)) and bit_stride(867) % 16 == 0
     assert np.array_equal(unpack_bits(p, 867), b)
     assert gaussian_width(0) == 0 and gaussian_width(6711) == 2319
+
+
+def test_gaussian_regularity_new_from_n_reports_empty_ranges():
+    """For n = 31..36 no prime of [n^3/2, n^3] satisfies q*alpha >= n (regev_discrete_gauss.rs:161-199, 270-297):
+    the reference's new_from_n would loop forever; the mirror raises MathError.  Neighbouring n still work."""
+    from crypto_amd.construction.pk_encryption import RegevWithDiscreteGaussianRegularity as R
+    from crypto_amd.math import MathError
+    with pytest.raises(MathError):
+        R.new_from_n(33, ctx=object())
+    for n in (30, 37):
+        p = R.new_from_n(n, ctx=object())
+        p.check_correctness(); p.check_security()
