@@ -358,9 +358,11 @@ __global__ __launch_bounds__(WV_THREADS) void qf_ring_wave_kernel(QfRingArgs a) 
                     int32_t sv = sj[lane + 64 * r];
                     uint64_t sq = (uint64_t)((int64_t)sv * (int64_t)sv);
                     nlo += (uint32_t)sq; nhi += sq >> 32;
-                    // sigma + off32 is in [0, 2^32): off32 = smallest multiple of q >= 2^31
-                    x[r] = LAZY ? wv_red32<false>((uint32_t)sv + a.off32, one_p, q)
-                                : wv_red32<true>((uint32_t)sv + a.off32, one_p, q);
+                    // off32 = smallest multiple of q >= 2^31 lies in [2^31, 2^31 + q): added to NEGATIVE
+                    // coefficients only (sv + off32 in [0, off32)); a non-negative sv is its own
+                    // 32-bit representative (adding off32 to it could wrap past 2^32)
+                    const uint32_t sr = sv < 0 ? (uint32_t)sv + a.off32 : (uint32_t)sv;
+                    x[r] = LAZY ? wv_red32<false>(sr, one_p, q) : wv_red32<true>(sr, one_p, q);
                 }
                 W::forward(x, lane, buf, twf, twg_f, q);
                 const uint2 *kh = (const uint2 *)a.key + (size_t)j * N;

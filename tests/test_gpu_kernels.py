@@ -161,6 +161,32 @@ def test_fdh_ring_verify(ctx, n, q, B):
     assert ok_ref[1] == 0 and ok_ref[0] == 1
 
 
+@pytest.mark.parametrize("n,q", [(1024, 2147473409), (256, 2013265921), (1024, 1073479681), (64, 257)])
+def test_fdh_ring_verify_full_range_sigma(ctx, n, q):
+    """sigma is a MatPolyOverZ (gpv_ring.rs:237 reduces it into [0,q)): coefficients over the whole
+    int32 range, INT32_MIN / INT32_MAX included, with q just below 2^31 and in (2^30, 2^31) -- the
+    wave kernel used to wrap positive coefficients >= 2^32 - off32 (round-1 advisor finding)."""
+    B = 3
+    k = (q - 1).bit_length()
+    mbar = k + 2
+    A = co.sample_uniform(SEED, 1, 0, mbar * n, q).reshape(mbar, n)
+    raw = co.sample_uniform(SEED, 7, 0, B * mbar * n, 2 ** 31 - 1).astype(np.int64) * 2 - (2 ** 31 - 1)
+    sigma = np.clip(raw, -2 ** 31, 2 ** 31 - 1).astype(np.int32).reshape(B, mbar, n)
+    sigma[0, 0, :4] = [2 ** 31 - 1, -2 ** 31, 2 ** 31 - 2, -1]
+    sigma[1, 1, :3] = [2 ** 32 - 2 * q - 1 if q > 2 ** 30 else 5, q - 1, -(q - 1)]
+    sigma[2] = 0
+    sigma[2, 2, 5] = 2 ** 31 - 1                          # norm 2^62 - 2^32 + 1: exactly at the bound below
+    bound = (2 ** 31 - 1) ** 2
+    zero_u = np.zeros((B, n), np.uint32)
+    t_ref, _ = co.fdh_ring_verify_batch(A, q, sigma, zero_u, bound)
+    ring = ctx.ring(n, q)
+    ok, t = ring.fdh_verify(ring.key(A), ctx.to_dev_i32(sigma), ctx.to_dev_u32(t_ref), bound, want_t=True)
+    _, ok_ref = co.fdh_ring_verify_batch(A, q, sigma, t_ref, bound)
+    assert np.array_equal(ctx.to_host_u32(t), t_ref)
+    assert np.array_equal(ctx.to_host_u8(ok), ok_ref)
+    assert ok_ref.tolist() == [0, 0, 1]                   # the first two exceed the norm bound
+
+
 def test_hash_to_mat_zq_sha256_kats(ctx):
     """construction/hash/sha256.rs:104,300-332 known answers, through the device kernel."""
     got = ctx.to_host_u32(ctx.hash_to_mat_zq_sha256(["Hello World!"], 2, 2, 7)).reshape(2, 2)
