@@ -46,6 +46,7 @@ SYMBOLS = {
     "qf_key_destroy": (None, [_vp]),
     "qf_key_dims": (_i, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "qf_key_u32_dev": (_i, [_vp, _pp, C.POINTER(_sz)]),
+    "qf_key_replicate": (_i, [_pp, _i, _vp, _pp]),
     "qf_matmul_modq_dev": (_i, [_vp, _vp, _vp, _i, _sz, _i, _u64, _vp, _vp, _vp]),
     "qf_matvec_modq_host": (_i, [_vp, _vp, _vp, _vp]),
     "qf_vecmat_modq_host": (_i, [_vp, _vp, _vp, _vp]),

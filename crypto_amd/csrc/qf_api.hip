@@ -109,6 +109,8 @@ void qf_ctx_destroy(qf_ctx *ctx) {
     hipStreamSynchronize(ctx->stream);
     if (ctx->ws) hipFree(ctx->ws);
     if (ctx->ws2) hipFree(ctx->ws2);
+    if (ctx->mv_acc) hipFree(ctx->mv_acc);
+    if (ctx->hostvec) hipFree(ctx->hostvec);
     if (ctx->flag) hipFree(ctx->flag);
     if (ctx->cdt) hipFree(ctx->cdt);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -236,6 +238,35 @@ int qf_key_dims(const qf_key *key, uint32_t *rows, uint32_t *cols, uint32_t *q) 
     if (q) *q = key->q;
     return QF_OK;
 }
+// One process driving several GPUs: the uint32 matrix goes from the source key's device to each
+// target context's device (peer copy over xGMI; a plain device copy when they share a device), the
+// digit planes are derived locally on every GPU -- the same "replicate once, recode locally" step
+// that one-process-per-GPU hosts do with qf_key_u32_dev + an RCCL broadcast + qf_key_upload_dev.
+int qf_key_replicate(qf_ctx *const *ctxs, int n, const qf_key *src, qf_key **out) {
+    if (!ctxs || n <= 0 || !src || !out) return QF_ERR_ARG;
+    for (int i = 0; i < n; i++) out[i] = nullptr;
+    for (int i = 0; i < n; i++) if (!ctxs[i]) return QF_ERR_ARG;
+    const size_t bytes = (size_t)src->rows * src->cols * 4;
+    for (int i = 0; i < n; i++) {
+        qf_ctx *ctx = ctxs[i];
+        int rc = QF_OK;
+        uint32_t *copy = nullptr;
+        if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc((void **)&copy, bytes) != hipSuccess) {
+            rc = qf_fail(ctx, QF_ERR_DEVICE, "key replicate: allocation on the target device failed");
+        } else {
+            hipError_t e = ctx->device == src->device
+                               ? hipMemcpyAsync(copy, src->u32, bytes, hipMemcpyDeviceToDevice, ctx->stream)
+                               : hipMemcpyPeerAsync(copy, ctx->device, src->u32, src->device, bytes, ctx->stream);
+            if (e != hipSuccess) { hipFree(copy); rc = qf_fail(ctx, QF_ERR_DEVICE, "key replicate: device-to-device copy failed"); }
+            else rc = key_build(ctx, copy, src->rows, src->cols, src->q, &out[i]);   // takes ownership of `copy`
+        }
+        if (rc) {
+            for (int j = 0; j < i; j++) { qf_key_destroy(out[j]); out[j] = nullptr; }
+            return rc;
+        }
+    }
+    return QF_OK;
+}
 int qf_key_u32_dev(const qf_key *key, const uint32_t **dev_ptr, size_t *bytes) {
     if (!key || !dev_ptr || !bytes) return QF_ERR_ARG;
     *dev_ptr = key->u32;
@@ -286,6 +317,7 @@ int qf_matmul_modq_dev(qf_ctx *ctx, const qf_key *key, const void *X_dev, int x_
 // ------------------------------------------------------------------ kernel (c)
 int qf_matvec_modq_dev(qf_ctx *ctx, const qf_key *key, const uint32_t *x_dev, uint32_t *y_dev) {
     if (!ctx || !key || !x_dev || !y_dev) return QF_ERR_ARG;
+    if (key->device != ctx->device) return qf_fail(ctx, QF_ERR_ARG, "matvec: key lives on another device");
     QF_BIND(ctx);
     return qf_launch_matvec(ctx, key, x_dev, y_dev);
 }
@@ -298,15 +330,19 @@ static int vec_host(qf_ctx *ctx, const qf_key *key, const uint32_t *x_host, uint
     if (!ctx || !key || !x_host || !y_host) return QF_ERR_ARG;
     QF_BIND(ctx);
     uint32_t nin = trans ? key->rows : key->cols, nout = trans ? key->cols : key->rows;
-    uint32_t *buf = nullptr;
-    QF_HIP(ctx, hipMalloc((void **)&buf, ((size_t)nin + nout) * 4 + 32));
-    uint32_t *x = buf, *y = buf + ((nin + 3) & ~3u);
+    // staging pooled in the context (grown on demand): single-message calls allocate nothing in steady state
+    const size_t words = (((size_t)nin + 3) & ~(size_t)3) + nout + 8;
+    if (words > ctx->hostvec_words) {
+        if (ctx->hostvec) { QF_HIP(ctx, hipStreamSynchronize(ctx->stream)); QF_HIP(ctx, hipFree(ctx->hostvec)); ctx->hostvec = nullptr; ctx->hostvec_words = 0; }
+        QF_HIP(ctx, hipMalloc((void **)&ctx->hostvec, words * 4 * 2));
+        ctx->hostvec_words = words * 2;
+    }
+    uint32_t *x = ctx->hostvec, *y = ctx->hostvec + ((nin + 3) & ~3u);
     int rc = QF_OK;
     if (hipMemcpyAsync(x, x_host, (size_t)nin * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = QF_ERR_DEVICE;
     if (!rc) rc = trans ? qf_launch_vecmat(ctx, key, x, y) : qf_launch_matvec(ctx, key, x, y);
     if (!rc && hipMemcpyAsync(y_host, y, (size_t)nout * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = QF_ERR_DEVICE;
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = QF_ERR_DEVICE;
-    hipFree(buf);
     return rc;
 }
 int qf_matvec_modq_host(qf_ctx *ctx, const qf_key *key, const uint32_t *x_host, uint32_t *y_host) {

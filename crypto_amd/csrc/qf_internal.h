@@ -13,8 +13,12 @@ struct qf_ctx {
     // scratch (grown on demand, owned by the context)
     void *ws = nullptr;       // recoded batch operand planes
     size_t ws_bytes = 0;
-    void *ws2 = nullptr;      // mat-vec partial sums / small staging
+    void *ws2 = nullptr;      // vec-mat partial sums
     size_t ws2_bytes = 0;
+    void *mv_acc = nullptr;   // mat-vec cross-workgroup sums: one uint64 per padded row, all-zero between launches
+    size_t mv_acc_bytes = 0;
+    uint32_t *hostvec = nullptr;  // staging of the *_host single-message entry points (x then y)
+    size_t hostvec_words = 0;
     uint32_t *flag = nullptr; // device error flag (range violations)
     // discrete-Gaussian inversion table of the last (n, s) asked for (qf_sample_discrete_gauss_dev)
     uint64_t *cdt = nullptr;

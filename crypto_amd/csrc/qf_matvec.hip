@@ -1,12 +1,12 @@
 // Kernel (c): HBM-streaming single-message products and the batched dot-product decryption.
-// These are byte-streaming kernels: every matrix / ciphertext word is read exactly once with
-// 16-byte-per-lane coalesced loads, products are accumulated exactly as split 64-bit sums
-// (low and high 32-bit halves of each 62-bit product are summed separately, so nothing can
-// overflow), and the reduction mod q happens once per output.
+// Byte-streaming kernels: every matrix / ciphertext byte is read exactly once with 16-byte-per-lane
+// coalesced loads.  y = A*x streams the key's int8 digit planes (v_dot4c_i32_i8 against the digits
+// of x); x^t*A and the decryption work on uint32 words with split 64-bit sums (low and high halves
+// of each 62-bit product summed separately, so nothing can overflow) reduced once per output.
+#include <cstdlib>
 #include "qf_internal.h"
 
 #define MV_BLOCK 256
-#define MV_CHUNK 4096  // columns handled by one workgroup of the mat-vec (16 per thread)
 
 struct Acc2 { uint64_t lo, hi; };
 __device__ __forceinline__ void acc_mad(Acc2 &a, uint32_t x, uint32_t y) {
@@ -19,73 +19,186 @@ __device__ __forceinline__ uint32_t acc_finish(uint64_t lo, uint64_t hi, const Q
     uint32_t h = qf_red_u64(hi, m), l = qf_red_u64(lo, m);
     return qf_addmod(qf_mulmod(h, m.r32, m), l, m.q);
 }
-__device__ __forceinline__ Acc2 block_sum(Acc2 a, Acc2 *sm) {
-    a.lo = qf_wave_sum_u64(a.lo);
-    a.hi = qf_wave_sum_u64(a.hi);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) sm[w] = a;
-    __syncthreads();
-    Acc2 t = {0, 0};
-    if (threadIdx.x == 0)
-        for (int i = 0; i < (int)(blockDim.x >> 6); i++) { t.lo += sm[i].lo; t.hi += sm[i].hi; }
-    return t;
-}
+// ---------------------------------------------------------------------------------------------
+// y = A*x on the key's int8 DIGIT PLANES (the same [rb][ks][la][64 lanes][16 B] fragment image
+// kernel (a) reads): ceil(bits(q)/8) bytes per matrix entry cross the HBM bus instead of the 4 of
+// the uint32 copy (SIS n=512, q=8,380,417: 18.1 MB instead of 24.1 MB), every wave instruction is
+// one contiguous 1-KiB fragment, and a workgroup owns a short run of k-steps of ONE row block, so
+// the SIS matrix becomes ~500 workgroups with every byte requested within the first microsecond.
+//
+//   workgroup (4 waves) = row block rbi x k-steps [ks0, ks0 + 4U): wave w owns k-steps ks0+4u+w.
+//   1. every lane issues its U*L fragment loads (16 B each) at once;
+//   2. meanwhile thread t recodes x[32 ks0 + t] into L balanced digits -> LDS digit rows;
+//   3. per fragment: L*L*4 v_dot4c_i32_i8 against the x digits of its 16 columns (digit pairs of
+//      equal weight share an int32 sum, as in the GEMM); recombined with the centred 2^(8s) mod q,
+//      reduced, summed over the two lane halves and the four waves -> one residue per row;
+//   4. cross-workgroup sum WITHOUT a second kernel and without a ticket: one returning 64-bit
+//      atomic add per row of (1 << 48 | residue) into the scratch word of that row; the add that
+//      finds nsplit-1 earlier arrivals in the top 16 bits holds the complete sum, writes y[row]
+//      and swaps the word back to 0 -- the scratch is all-zero again when the kernel ends.  Data
+//      moves between workgroups through device-scope atomics only, so nothing depends on
+//      placement, dispatch order or cache state (MI355X_MICROARCH.md, inter-workgroup visibility).
+// Scratch: one uint64 per padded row, zero before the launch (qf_ctx owns one, zeroed when it is
+// allocated).
+// ---------------------------------------------------------------------------------------------
+#define MVP_THREADS 256
+struct QfMvpArgs {
+    const int8_t *planes;
+    const uint32_t *x;
+    uint32_t *y;
+    unsigned long long *acc;
+    uint32_t rb, ks, rows, cols, nsplit;
+    int32_t cs[8];
+    QfMod mod;
+};
 
-// y = A*x : grid (chunks, rows); partial[row][chunk] = split sum over the chunk's columns
-__global__ __launch_bounds__(MV_BLOCK) void qf_matvec_partial(const uint32_t *__restrict__ A,
-                                                              uint32_t rows, uint32_t cols,
-                                                              const uint32_t *__restrict__ x,
-                                                              Acc2 *__restrict__ partial, uint32_t nchunk) {
-    __shared__ Acc2 sm[MV_BLOCK / 64];
-    const uint32_t row = blockIdx.y, chunk = blockIdx.x;
-    const uint32_t c0 = chunk * MV_CHUNK;
-    const uint32_t *a = A + (size_t)row * cols;
-    Acc2 acc = {0, 0};
-    const bool vec_ok = ((((size_t)row * cols) & 3) == 0) && ((((uintptr_t)A) & 15) == 0) && ((((uintptr_t)x) & 15) == 0);
+template <int L, int U>
+__global__ __launch_bounds__(MVP_THREADS) void qf_matvec_planes_kernel(QfMvpArgs a) {
+    constexpr int KW = 4 * U;                       // k-steps per workgroup
+    constexpr int S = 2 * L - 1;
+    __shared__ __attribute__((aligned(16))) uint8_t xd[L][KW * 32];
+    __shared__ uint32_t part[4][32];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, h = lane >> 5;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t rbi = blockIdx.x / a.nsplit, sp = blockIdx.x % a.nsplit;
+    const uint32_t ks0 = sp * KW;
+
+    // x is requested FIRST: vector loads return in order, so its recode then runs while the fragments
+    // are still on their way instead of behind them
+    constexpr int XPT = (KW * 32 + MVP_THREADS - 1) / MVP_THREADS;   // x values per thread (1 or 2)
+    uint32_t xraw[XPT];
 #pragma unroll
-    for (int i = 0; i < MV_CHUNK / (MV_BLOCK * 4); i++) {
-        uint32_t c = c0 + (i * MV_BLOCK + threadIdx.x) * 4;
-        if (vec_ok && c + 4 <= cols) {
-            uint4 av = *(const uint4 *)(a + c), xv = *(const uint4 *)(x + c);
-            acc_mad(acc, av.x, xv.x); acc_mad(acc, av.y, xv.y);
-            acc_mad(acc, av.z, xv.z); acc_mad(acc, av.w, xv.w);
-        } else {
-            for (uint32_t k = c; k < c + 4 && k < cols; k++) acc_mad(acc, a[k], x[k]);
+    for (int j = 0; j < XPT; j++) {
+        const uint32_t t = tid + j * MVP_THREADS, k = ks0 * 32 + t;
+        xraw[j] = (t < KW * 32 && k < a.cols) ? a.x[k] : 0u;
+    }
+    // 1. the fragments (k-steps past the key's padded width are skipped: wave-uniform)
+    v4i kf[U][L];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const uint32_t ksi = ks0 + 4 * u + wave;
+        const v4i *src = (const v4i *)(a.planes + (((size_t)rbi * a.ks + (ksi < a.ks ? ksi : a.ks - 1)) * L * 64 + lane) * 16);
+#pragma unroll
+        for (int l = 0; l < L; l++) kf[u][l] = src[64 * l];
+    }
+    // 2. this workgroup's slice of x as balanced digits (same recode as qf_recode_kernel)
+#pragma unroll
+    for (int j = 0; j < XPT; j++) {
+        const uint32_t t = tid + j * MVP_THREADS;
+        if (t >= KW * 32) break;
+        // entries past the key's columns arrive as 0 (they only meet zero-padded key digits anyway)
+        const uint32_t c = qf_red_u64(xraw[j], a.mod);
+        int64_t maxpos = 0;
+#pragma unroll
+        for (int i = 0; i < L; i++) maxpos = maxpos * 256 + 127;
+        int64_t rep = (int64_t)c <= maxpos ? (int64_t)c : (int64_t)c - (int64_t)a.mod.q;
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+            const int64_t d = ((rep + 128) & 255) - 128;
+            xd[l][t] = (uint8_t)(d & 255);
+            rep = (rep - d) >> 8;
         }
     }
-    Acc2 t = block_sum(acc, sm);
-    if (threadIdx.x == 0) partial[(size_t)row * nchunk + chunk] = t;
-}
-__global__ void qf_matvec_finish(const Acc2 *__restrict__ partial, uint32_t n, uint32_t nchunk,
-                                 QfMod mod, uint32_t *__restrict__ y) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint64_t lo = 0, hi = 0;
-    for (uint32_t c = 0; c < nchunk; c++) { lo += partial[(size_t)i * nchunk + c].lo; hi += partial[(size_t)i * nchunk + c].hi; }
-    y[i] = acc_finish(lo, hi, mod);
+    __syncthreads();
+    // 3. digit products
+    int acc[S];
+#pragma unroll
+    for (int s = 0; s < S; s++) acc[s] = 0;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const uint32_t ksi = ks0 + 4 * u + wave;
+        if (ksi >= a.ks) continue;
+#pragma unroll
+        for (int lb = 0; lb < L; lb++) {
+            const v4i xs = *(const v4i *)&xd[lb][(4 * u + wave) * 32 + 16 * h];
+#pragma unroll
+            for (int la = 0; la < L; la++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[la + lb] = __builtin_amdgcn_sdot4(kf[u][la][i], xs[i], acc[la + lb], false);
+        }
+    }
+    int64_t v = 0;
+#pragma unroll
+    for (int s = 0; s < S; s++) v += (int64_t)acc[s] * (int64_t)a.cs[s];   // |acc| < 2^25, |cs| < 2^30
+    uint32_t r = qf_red_i64(v, a.mod);
+    r = qf_addmod(r, (uint32_t)__shfl_xor((int)r, 32, 64), a.mod.q);
+    if (lane < 32) part[wave][lane] = r;
+    __syncthreads();
+    if (tid < 32) {
+        r = qf_addmod(qf_addmod(part[0][tid], part[1][tid], a.mod.q), qf_addmod(part[2][tid], part[3][tid], a.mod.q), a.mod.q);
+        const uint32_t row = rbi * 32 + tid;
+        // 4. (padded rows take part too: they are what returns their scratch words to zero)
+        uint64_t total = r;
+        bool last = true;
+        if (a.nsplit > 1) {
+            unsigned long long *w = a.acc + row;
+            const unsigned long long old = __hip_atomic_fetch_add(w, (1ull << 48) | (unsigned long long)r,
+                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (uint32_t)(old >> 48) == a.nsplit - 1;
+            total = (old & 0xFFFFFFFFFFFFull) + r;
+            if (last) (void)__hip_atomic_exchange(w, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (last && row < a.rows) a.y[row] = qf_red_u64(total, a.mod);
+    }
 }
 
-// y = A*x in ONE launch when every row starts 16-byte aligned: a workgroup streams a whole row
-// (all its loads are independent and issued back to back), reduces it and writes the canonical
-// residue -- no partial-sum buffer, no second kernel.
-__global__ __launch_bounds__(MV_BLOCK) void qf_matvec_rows(const uint32_t *__restrict__ A, uint32_t cols,
-                                                           const uint32_t *__restrict__ x, QfMod mod,
-                                                           uint32_t *__restrict__ y) {
-    __shared__ Acc2 sm[MV_BLOCK / 64];
-    const uint32_t row = blockIdx.x;
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 *a = (const u32x4 *)(A + (size_t)row * cols);
-    const u32x4 *xv4 = (const u32x4 *)x;
-    const uint32_t nv = cols >> 2;  // cols % 4 == 0 (checked by the launcher)
-    Acc2 acc = {0, 0};
-#pragma unroll 4
-    for (uint32_t i = threadIdx.x; i < nv; i += MV_BLOCK) {
-        const u32x4 av = __builtin_nontemporal_load(a + i), xv = xv4[i];
-        acc_mad(acc, av.x, xv.x); acc_mad(acc, av.y, xv.y);
-        acc_mad(acc, av.z, xv.z); acc_mad(acc, av.w, xv.w);
+template <int L>
+static int mvp_launch(qf_ctx *ctx, const QfMvpArgs &a0, uint32_t ks) {
+    // k-steps per wave: the smallest U that brings the grid to <= 768 workgroups.  Measured on the
+    // cold SIS key (profiles/r2/matvec_variants.log): 1,472 / 736 / 496 / 368 workgroups take 7.1 / 6.1 /
+    // 6.1 / 6.4 us -- fewer arrivals per scratch word (the atomics of one row block contend on two
+    // 128-byte lines) against fewer, longer workgroups.  Default cache policy: non-temporal loads
+    // were 0.1-0.3 us slower here and would keep a re-used key out of the Infinity Cache.
+    int U = 1;
+    while (U < 4 && (uint64_t)a0.rb * ((ks + 4 * U - 1) / (4 * U)) > 768) U++;
+    if (const char *e = getenv("QF_MATVEC_U")) { int v = atoi(e); if (v >= 1 && v <= 4) U = v; }   // experiments
+    QfMvpArgs a = a0;
+    a.nsplit = (ks + 4 * U - 1) / (4 * U);
+    if (a.nsplit >= 65536) return qf_fail(ctx, QF_ERR_NOTSUP, "matvec: more than 2^16 k-chunks per row block");
+    const dim3 grid(a.rb * a.nsplit), block(MVP_THREADS);
+    QfTimer t(ctx, &ctx->ms_matvec);
+    switch (U) {
+        case 1: hipLaunchKernelGGL((qf_matvec_planes_kernel<L, 1>), grid, block, 0, ctx->stream, a); break;
+        case 2: hipLaunchKernelGGL((qf_matvec_planes_kernel<L, 2>), grid, block, 0, ctx->stream, a); break;
+        case 3: hipLaunchKernelGGL((qf_matvec_planes_kernel<L, 3>), grid, block, 0, ctx->stream, a); break;
+        default: hipLaunchKernelGGL((qf_matvec_planes_kernel<L, 4>), grid, block, 0, ctx->stream, a); break;
     }
-    Acc2 t = block_sum(acc, sm);
-    if (threadIdx.x == 0) y[row] = acc_finish(t.lo, t.hi, mod);
+    QF_HIP(ctx, hipGetLastError());
+    return QF_OK;
+}
+
+// acc: rb*32 zeroed uint64 words on the key's device
+static int mvp_run(qf_ctx *ctx, const qf_key *key, const uint32_t *x, uint32_t *y, unsigned long long *acc) {
+    QfMvpArgs a;
+    a.planes = key->planes; a.x = x; a.y = y; a.acc = acc;
+    a.rb = key->rb; a.ks = key->ks; a.rows = key->rows; a.cols = key->cols; a.nsplit = 1;
+    a.mod = key->mod;
+    uint64_t p = 1 % key->q;
+    for (int s = 0; s < 8; s++) {
+        int64_t c = (int64_t)p;
+        if (c > (int64_t)(key->q / 2)) c -= key->q;
+        a.cs[s] = (int32_t)c;
+        p = (p * 256) % key->q;
+    }
+    if ((uint64_t)key->rb * ((key->ks + 3) / 4) > 0x7fffffffull) return qf_fail(ctx, QF_ERR_NOTSUP, "matvec: key too large");
+    switch (key->la) {
+        case 1: return mvp_launch<1>(ctx, a, key->ks);
+        case 2: return mvp_launch<2>(ctx, a, key->ks);
+        case 3: return mvp_launch<3>(ctx, a, key->ks);
+        case 4: return mvp_launch<4>(ctx, a, key->ks);
+    }
+    return qf_fail(ctx, QF_ERR_NOTSUP, "matvec: digit count not instantiated");
+}
+
+int qf_launch_matvec(qf_ctx *ctx, const qf_key *key, const uint32_t *x, uint32_t *y) {
+    const size_t need = (size_t)key->rb * 32 * sizeof(unsigned long long);
+    if (need > ctx->mv_acc_bytes) {   // grown on demand, zeroed once: the kernel leaves it zero
+        if (ctx->mv_acc) { QF_HIP(ctx, hipStreamSynchronize(ctx->stream)); QF_HIP(ctx, hipFree(ctx->mv_acc)); ctx->mv_acc = nullptr; ctx->mv_acc_bytes = 0; }
+        QF_HIP(ctx, hipMalloc(&ctx->mv_acc, need));
+        ctx->mv_acc_bytes = need;
+        QF_HIP(ctx, hipMemsetAsync(ctx->mv_acc, 0, need, ctx->stream));
+    }
+    return mvp_run(ctx, key, x, y, (unsigned long long *)ctx->mv_acc);
 }
 
 // y^t = x^t*A : grid (column tiles of 1024, row chunks); thread owns 4 adjacent columns
@@ -123,28 +236,6 @@ __global__ void qf_vecmat_finish(const Acc2 *__restrict__ partial, uint32_t cols
     y[j] = acc_finish(lo, hi, mod);
 }
 
-int qf_launch_matvec(qf_ctx *ctx, const qf_key *key, const uint32_t *x, uint32_t *y) {
-    if (key->rows >= 128 && (key->cols & 3) == 0 && (((uintptr_t)key->u32) & 15) == 0 && (((uintptr_t)x) & 15) == 0) {
-        QfTimer t(ctx, &ctx->ms_matvec);
-        hipLaunchKernelGGL(qf_matvec_rows, dim3(key->rows), dim3(MV_BLOCK), 0, ctx->stream, key->u32, key->cols, x,
-                           key->mod, y);
-        QF_HIP(ctx, hipGetLastError());
-        return QF_OK;
-    }
-    uint32_t nchunk = (key->cols + MV_CHUNK - 1) / MV_CHUNK;
-    int rc = qf_ws2_reserve(ctx, (size_t)key->rows * nchunk * sizeof(Acc2));
-    if (rc) return rc;
-    dim3 grid(nchunk, key->rows), block(MV_BLOCK);
-    {
-        QfTimer t(ctx, &ctx->ms_matvec);
-        hipLaunchKernelGGL(qf_matvec_partial, grid, block, 0, ctx->stream, key->u32, key->rows, key->cols, x,
-                           (Acc2 *)ctx->ws2, nchunk);
-    }
-    hipLaunchKernelGGL(qf_matvec_finish, dim3((key->rows + 255) / 256), dim3(256), 0, ctx->stream,
-                       (const Acc2 *)ctx->ws2, key->rows, nchunk, key->mod, y);
-    QF_HIP(ctx, hipGetLastError());
-    return QF_OK;
-}
 int qf_launch_vecmat(qf_ctx *ctx, const qf_key *key, const uint32_t *x, uint32_t *y) {
     uint32_t nchunk = (key->rows + VM_ROWS - 1) / VM_ROWS;
     int rc = qf_ws2_reserve(ctx, (size_t)key->cols * nchunk * sizeof(Acc2));

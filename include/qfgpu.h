@@ -88,6 +88,13 @@ int qf_key_dims(const qf_key *key, uint32_t *rows, uint32_t *cols, uint32_t *q);
 /* device pointer + size of the row-major uint32 copy (rows x cols of the key as stored):
  * this is the buffer a multi-GPU host broadcasts with RCCL before qf_key_upload_dev. */
 int qf_key_u32_dev(const qf_key *key, const uint32_t **dev_ptr, size_t *bytes);
+/* Multi-GPU step of the path (the reference is single-device and has no counterpart):
+ * replicate a key that lives on one GPU to n contexts (normally one per GPU of the node) in ONE call.
+ * The uint32 matrix crosses xGMI once per target (peer copy enqueued on the target context's stream);
+ * every GPU derives its digit planes locally.  out_keys[i] belongs to ctxs[i]'s device; on error
+ * nothing is left allocated.  Hosts that run one PROCESS per GPU broadcast the buffer of
+ * qf_key_u32_dev with RCCL and call qf_key_upload_dev on each rank instead (bench.py does). */
+int qf_key_replicate(qf_ctx *const *ctxs, int n, const qf_key *src_key, qf_key **out_keys);
 
 /* Kernel (a): batched product on int8 MFMA.
  *   out[b][i] = sum_j key[i][j]*X[b][j]  (+ addend[b][i])  (+ (msg[b]&1)*floor(q/2) if i==rows-1)   mod q
@@ -108,7 +115,9 @@ int qf_matmul_modq_dev(qf_ctx *ctx, const qf_key *key, const void *X_dev, int x_
 /* Kernel (c): HBM-streaming single-message products (host vectors in/out, synchronous).
  *   qf_matvec_modq_host : y = key * x          regev.rs:404, lpr.rs:420, sis.rs:166, dual_regev.rs:354
  *   qf_vecmat_modq_host : y^t = x^t * key      regev.rs:367, lpr.rs:363, dual_regev.rs:403
- * x has cols (resp. rows) entries, y rows (resp. cols). */
+ * x has cols (resp. rows) entries (any uint32_t value is reduced mod q), y rows (resp. cols).
+ * The mat-vec streams the key's int8 digit planes (ceil(bits(q)/8) bytes per entry); its
+ * cross-workgroup sums use a small scratch owned by the context (allocated on first use). */
 int qf_matvec_modq_host(qf_ctx *ctx, const qf_key *key, const uint32_t *x_host, uint32_t *y_host);
 int qf_vecmat_modq_host(qf_ctx *ctx, const qf_key *key, const uint32_t *x_host, uint32_t *y_host);
 /* device-pointer forms (asynchronous) used by the benchmarks */

@@ -32,6 +32,20 @@ def test_matvec_vecmat(ctx, rows, cols, q):
     assert np.array_equal(ctx.vecmat(key, s), co.vecmat(s, A, q))
 
 
+@pytest.mark.parametrize("U", [1, 2, 3, 4])
+@pytest.mark.parametrize("rows,cols,q", [(512, 11776, 8380417), (257, 6168, 16777213), (70, 1300, 2147483629), (33, 50, 251)])
+def test_matvec_every_chunking(ctx, monkeypatch, rows, cols, q, U):
+    """Kernel (c) on the digit planes with 1..4 k-steps per wave (QF_MATVEC_U): every grid shape the
+    launcher can pick, partial last chunks, 1..4 digits per entry, x with arbitrary uint32 values."""
+    monkeypatch.setenv("QF_MATVEC_U", str(U))
+    A = co.sample_uniform(SEED, 1, 7, rows * cols, q).reshape(rows, cols)
+    key = ctx.key_upload(A, q)
+    x = co.sample_uniform(SEED, 6, U, cols, 2 ** 32 - 1)            # any uint32 is reduced mod q
+    want = co.matvec(A, (x.astype(np.uint64) % q).astype(np.uint32), q)
+    for _ in range(2):                                              # twice: the scratch must come back clean
+        assert np.array_equal(ctx.matvec(key, x), want)
+
+
 @pytest.mark.parametrize("n,m,q,B", [(13, 154, 1427, 70), (50, 867, 124991, 300), (256, 6168, 16777213, 513),
                                      (3, 16, 13, 5), (64, 1000, 2147483629, 40), (31, 129, 251, 33),
                                      # packed remainder block (rows mod 32 = r, r*digits <= 32): r*LA = 32 exactly with
