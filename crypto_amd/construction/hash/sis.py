@@ -25,7 +25,7 @@ class SISHash:
         n, m, q = int(n), int(m), int(q)
         if n < 1:
             raise MathError("n must be chosen bigger than 0.")
-        rng = Randomness(seed, ctx) if seed is not None else Randomness(ctx=ctx)
+        rng = Randomness(seed, ctx)
         return cls(MatZq(rng.uniform(1, n * m, q).reshape(n, m), q), ctx)
 
     def check_security(self):

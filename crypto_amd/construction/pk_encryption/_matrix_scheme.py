@@ -12,7 +12,7 @@ from ...runtime import Randomness, default_context
 class MatrixSchemeMixin:
     def _init_runtime(self, ctx=None, seed=None, noise_model=None):
         self._ctx = ctx
-        self.rng = Randomness(seed, ctx) if seed is not None else Randomness(ctx=ctx)
+        self.rng = Randomness(seed, ctx)   # seed None -> a fresh os.urandom seed per object
         set_noise_model(self, noise_model)
 
     @property
@@ -45,11 +45,12 @@ class MatrixSchemeMixin:
 
 
 def set_noise_model(scheme, noise_model):
-    """noise_model: None / "irwin_hall" (the seeded benchmark generator's stand-in) or "discrete_gauss"
-    (D_{Z, alpha*q} with security parameter n, as the reference samples chi: regev.rs:356-363)."""
-    if noise_model in (None, "irwin_hall"):
+    """noise_model: None / "discrete_gauss" (default: D_{Z, alpha*q} with security parameter n, as the
+    reference samples chi -- regev.rs:356-363, lpr.rs:342-360, ring_lpr.rs:374-388) or "irwin_hall"
+    (the bounded stand-in of the benchmark generator, SURVEY 8d: explicit opt-in)."""
+    if noise_model == "irwin_hall":
         scheme.rng.gauss = None
-    elif noise_model == "discrete_gauss":
+    elif noise_model in (None, "discrete_gauss"):
         scheme.rng.gauss = (int(scheme.n), float(scheme.alpha * getattr(scheme, "q_int", scheme.q)))
     else:
         raise ValueError("noise_model must be 'irwin_hall' or 'discrete_gauss'")

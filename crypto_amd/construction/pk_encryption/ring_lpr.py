@@ -22,7 +22,7 @@ class RingLPR(PKEncryptionScheme):
         self.q = new_anticyclic(self.n, self.q_int)
         self.alpha = as_fraction(alpha)
         self._ctx = ctx
-        self.rng = Randomness(seed, ctx) if seed is not None else Randomness(ctx=ctx)
+        self.rng = Randomness(seed, ctx)
         self._ring = None
         set_noise_model(self, noise_model)
 

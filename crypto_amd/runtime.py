@@ -1,18 +1,28 @@
-"""Process-wide default device context and the seeded randomness the scheme layer draws from.
+"""Process-wide default device context and the randomness the scheme layer draws from.
 
-The reference samples from an unseeded RNG at every call (e.g. regev.rs:352-364,401).  Here the
-scheme objects own a `Randomness` (master seed + per-stream counters over the SplitMix64
-counter-mode generator of include/qfgpu.h), so that every run -- GPU path and CPU oracle alike
--- consumes the same inputs.  Streams: 1 uniform A / a, 2 secret, 3 x / r, 4 noise e,
-5 messages, 6 free operands.
+The reference samples from the OS's RNG at every call (e.g. regev.rs:352-364,401).  Here a scheme
+object owns a `Randomness`: a 64-bit seed + per-stream counters over the SplitMix64 counter-mode
+generator of include/qfgpu.h.  With an explicit `seed=` (tests, bench, oracle parity) every run --
+GPU path and CPU oracle alike -- consumes the same inputs; WITHOUT one, each object draws a fresh
+seed from os.urandom, so two default-constructed schemes never share keys or encryption
+randomness.  SplitMix64 is a benchmark/test generator, NOT a CSPRNG: the drop-in keeps the
+reference's arithmetic, and a deployment that needs confidentiality supplies its own randomness
+through the explicit-randomness arguments (`enc(pk, msg, x=...)`, `enc_batch(..., x_bits=...)`).
+Streams: 1 uniform A / a, 2 secret, 3 x / r, 4 noise e, 5 messages, 6 free operands.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import numpy as np
 
-MASTER_SEED = 0x5146414C4C  # "QFALL"
+MASTER_SEED = 0x5146414C4C  # "QFALL": the seed tests and benches pass EXPLICITLY; never a default
+
+
+def fresh_seed() -> int:
+    """64 bits from the OS, for objects constructed without a seed."""
+    return int.from_bytes(os.urandom(8), "little")
 
 _default_ctx = None
 
@@ -36,8 +46,8 @@ def set_default_context(ctx):
 class Randomness:
     """Counter-mode draws; each stream advances its own counter so draws never overlap."""
 
-    def __init__(self, seed: int = MASTER_SEED, ctx=None):
-        self.seed = int(seed)
+    def __init__(self, seed: Optional[int] = None, ctx=None):
+        self.seed = fresh_seed() if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF
         self._ctx = ctx
         self.pos = {}
 
@@ -54,10 +64,10 @@ class Randomness:
         first = self._take(stream, count)
         return self.ctx.to_host_u32(self.ctx.sample_uniform(self.seed, stream, first, count, q))
 
-    # Noise model of chi: "irwin_hall" (default) = the benchmark generator's Gaussian stand-in of
-    # SURVEY 8d, sum of 4 uniforms in [-W, W]; "discrete_gauss" = D_{Z,s} with the reference's
+    # Noise model of chi: "discrete_gauss" (the schemes' default) = D_{Z,s} with the reference's
     # parameters (n, s = alpha*q) -- what MatZq::sample_discrete_gauss(.., q, n, 0, s) draws
-    # (regev.rs:356-363).  Set through the schemes' noise_model argument.
+    # (regev.rs:356-363); "irwin_hall" = the benchmark generator's Gaussian stand-in of SURVEY 8d,
+    # sum of 4 uniforms in [-W, W] (explicit opt-in).  Set through the schemes' noise_model argument.
     gauss = None    # (n, s) when the model is "discrete_gauss"
 
     def noise_dev(self, stream: int, count: int, q: int, W: int):

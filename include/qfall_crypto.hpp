@@ -17,6 +17,8 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstring>
+#include <random>
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
@@ -29,7 +31,16 @@ namespace qfall {
 struct Panic : std::runtime_error { using std::runtime_error::runtime_error; };
 struct MathError : std::runtime_error { using std::runtime_error::runtime_error; };
 
-constexpr uint64_t MASTER_SEED = 0x5146414C4CULL;  // "QFALL"
+constexpr uint64_t MASTER_SEED = 0x5146414C4CULL;  // "QFALL": what tests and benches pass EXPLICITLY; never a default
+// Seed of an object constructed without one: 64 fresh bits from the OS, so that two default-constructed
+// schemes never share keys or encryption randomness (the reference draws OS randomness at every call,
+// regev.rs:352-364,401).  The generator behind it (SplitMix64 in counter mode, include/qfgpu.h) is a
+// benchmark/test generator, not a CSPRNG: a deployment that needs confidentiality passes its own
+// randomness through the explicit-randomness arguments (enc(pk, msg, &x), enc_batch(.., x_bits)).
+inline uint64_t fresh_seed() {
+    std::random_device rd;
+    return ((uint64_t)rd() << 32) ^ (uint64_t)rd();
+}
 
 // ---------------------------------------------------------------------------------------------
 // value types at the seam (qfall-math MatZq / MatZ / PolynomialRingZq / MatPolyOverZ)
@@ -87,17 +98,48 @@ class Device {
     explicit Device(int device = 0) {
         if (qf_ctx_create(device, nullptr, &ctx_) != QF_OK) throw Panic("no HIP device: there is no CPU fallback");
     }
-    ~Device() { qf_ctx_destroy(ctx_); }
+    ~Device() {
+        for (auto &c : cache_) qf_key_destroy(c.k);
+        qf_ctx_destroy(ctx_);
+    }
     Device(const Device &) = delete;
     Device &operator=(const Device &) = delete;
     qf_ctx *ctx() const { return ctx_; }
+    // The digit planes of a public matrix are derived data: upload + recode once per DISTINCT matrix and
+    // keep the handle (the reference passes `&pk` to every enc; re-uploading 6 MB per call would dominate
+    // single-message calls).  Hits are confirmed by comparing the full contents, so a stale or colliding
+    // entry can never be used; the 8 most recently used matrices stay resident.
+    qf_key *cached_key(const MatZq &m, bool transpose = false) const {
+        uint64_t h = 1469598103934665603ull;
+        for (uint32_t v : m.e) { h ^= v; h *= 1099511628211ull; }
+        for (auto &c : cache_)
+            if (c.hash == h && c.rows == m.rows && c.cols == m.cols && c.q == m.q && c.tr == transpose &&
+                c.e.size() == m.e.size() && std::memcmp(c.e.data(), m.e.data(), m.e.size() * 4) == 0) {
+                c.stamp = ++clock_;
+                return c.k;
+            }
+        qf_key *k = nullptr;
+        check(qf_key_upload_host(ctx_, m.e.data(), m.rows, m.cols, m.q, transpose ? 1 : 0, &k));
+        if (cache_.size() >= 8) {
+            size_t old = 0;
+            for (size_t i = 1; i < cache_.size(); i++) if (cache_[i].stamp < cache_[old].stamp) old = i;
+            qf_key_destroy(cache_[old].k);
+            cache_.erase(cache_.begin() + (long)old);
+        }
+        cache_.push_back(KeyEntry{m.rows, m.cols, m.q, transpose, h, m.e, k, ++clock_});
+        return k;
+    }
+    size_t cached_keys() const { return cache_.size(); }
     void check(int rc) const {
         if (rc != QF_OK) throw Panic(std::string("qfgpu error ") + std::to_string(rc) + ": " + qf_last_error(ctx_));
     }
     void sync() const { check(qf_sync(ctx_)); }
 
   private:
+    struct KeyEntry { uint32_t rows, cols, q; bool tr; uint64_t hash; std::vector<uint32_t> e; qf_key *k; uint64_t stamp; };
     qf_ctx *ctx_ = nullptr;
+    mutable std::vector<KeyEntry> cache_;
+    mutable uint64_t clock_ = 0;
 };
 
 template <class T>
@@ -142,7 +184,7 @@ class DevKey {  // MatZq resident on the device (qf_key)
 // seeded draws (streams: 1 uniform A/a, 2 secret, 3 x/r, 4 noise e, 5 messages, 6 free operands)
 class Randomness {
   public:
-    Randomness(const Device &d, uint64_t seed = MASTER_SEED) : dev_(&d), seed_(seed) {}
+    Randomness(const Device &d, uint64_t seed = fresh_seed()) : dev_(&d), seed_(seed) {}
     uint64_t seed() const { return seed_; }
     uint64_t take(uint32_t stream, uint64_t count) { uint64_t f = pos_[stream & 15]; pos_[stream & 15] += count; return f; }
     std::vector<uint32_t> uniform(uint32_t stream, uint64_t count, uint32_t q) {
@@ -150,9 +192,9 @@ class Randomness {
         dev_->check(qf_sample_uniform_dev(dev_->ctx(), seed_, stream, take(stream, count), count, q, b.get()));
         return b.download();
     }
-    // chi: the benchmark generator's stand-in (sum of 4 uniforms in [-W, W]; default), or -- after
-    // use_discrete_gauss(n, s) -- D_{Z,s} as MatZq::sample_discrete_gauss(.., q, n, 0, s) draws it
-    // (regev.rs:356-363, lpr.rs:342-360); e.g. scheme.randomness().use_discrete_gauss(n, alpha*q)
+    // chi: D_{Z,s} as MatZq::sample_discrete_gauss(.., q, n, 0, s) draws it (regev.rs:356-363,
+    // lpr.rs:342-360) -- the schemes select it with (n, alpha*q) when they are constructed -- or, after
+    // use_irwin_hall(), the benchmark generator's bounded stand-in (sum of 4 uniforms in [-W, W])
     void use_discrete_gauss(uint32_t n, double s) { gauss_n_ = n; gauss_s_ = s; }
     void use_irwin_hall() { gauss_n_ = 0; }
     std::vector<uint32_t> noise(uint32_t stream, uint64_t count, uint32_t q, uint32_t W) {
@@ -180,6 +222,15 @@ class Randomness {
     uint32_t gauss_n_ = 0;
     double gauss_s_ = 0.0;
 };
+
+// chi of a freshly constructed scheme: the reference's D_{Z, alpha*q} whenever the sampler supports the
+// parameters (n >= 2, support s*log2(n) in [1, 2^21]); otherwise the bounded stand-in stays
+inline void default_noise(Randomness &rng, uint32_t n, double s) {
+    if (n >= 2 && s > 0.0) {
+        const double support = std::ceil(s * std::log2((double)n));
+        if (support >= 1.0 && support <= (double)(1 << 21)) rng.use_discrete_gauss(n, s);
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // helpers shared by the parameter rules
@@ -240,9 +291,10 @@ class Regev : public PKEncryptionScheme<Regev, MatZq, MatZq, MatZq> {
   public:
     uint32_t n, m, q;
     double alpha;
-    Regev(const Device &d, uint32_t n_, uint32_t m_, uint32_t q_, double alpha_, uint64_t seed = MASTER_SEED)
+    Regev(const Device &d, uint32_t n_, uint32_t m_, uint32_t q_, double alpha_, uint64_t seed = fresh_seed())
         : n(n_), m(m_), q(q_), alpha(alpha_), dev(&d), rng(d, seed) {            // Regev::new regev.rs:87-99
         if (q <= 1) throw Panic("modulus must be > 1");
+        default_noise(rng, n, alpha * q);
     }
     static Regev default_(const Device &d) { return Regev(d, 13, 154, 1427, 0.01); }          // regev.rs:317-324
     static Regev secure128(const Device &d) { return Regev(d, 230, 5313, 7764299, 0.0011); }  // regev.rs:301-303
@@ -287,8 +339,8 @@ class Regev : public PKEncryptionScheme<Regev, MatZq, MatZq, MatZq> {
         std::vector<uint32_t> x = x_in ? *x_in : rng.bits(3, m);
         if (x.size() != m) throw Panic("mismatching matrix dimensions");
         MatZq c(n + 1, 1, q);
-        DevKey k(*dev, pk);
-        dev->check(qf_matvec_modq_host(dev->ctx(), k.get(), x.data(), c.e.data()));
+        qf_key *k = dev->cached_key(pk);
+        dev->check(qf_matvec_modq_host(dev->ctx(), k, x.data(), c.e.data()));
         c.set_entry(-1, 0, (uint64_t)c.get_entry(-1, 0) + (uint64_t)message_bit(message) * (q / 2));
         return c;
     }
@@ -304,10 +356,10 @@ class Regev : public PKEncryptionScheme<Regev, MatZq, MatZq, MatZq> {
         check_pk(pk);
         const uint64_t B = msg_bits.size();
         if (x_bits.size() != B * bit_stride(m)) throw Panic("mismatching randomness dimensions");
-        DevKey k(*dev, pk);
+        qf_key *k = dev->cached_key(pk);
         DevBuf<uint8_t> dx(*dev, x_bits), dm(*dev, msg_bits);
         DevBuf<uint32_t> out(*dev, B * (n + 1));
-        dev->check(qf_matmul_modq_dev(dev->ctx(), k.get(), dx.get(), QF_X_BITS, bit_stride(m), 1, B, nullptr, dm.get(), out.get()));
+        dev->check(qf_matmul_modq_dev(dev->ctx(), k, dx.get(), QF_X_BITS, bit_stride(m), 1, B, nullptr, dm.get(), out.get()));
         return out;
     }
     std::vector<uint8_t> dec_batch(const MatZq &sk, const uint32_t *C_dev, uint64_t B) {
@@ -334,8 +386,8 @@ class DualRegev : public PKEncryptionScheme<DualRegev, MatZq, MatZ, MatZq> {
   public:
     uint32_t n, m, q;
     double alpha;
-    DualRegev(const Device &d, uint32_t n_, uint32_t m_, uint32_t q_, double alpha_, uint64_t seed = MASTER_SEED)
-        : n(n_), m(m_), q(q_), alpha(alpha_), dev(&d), rng(d, seed) { if (q <= 1) throw Panic("modulus must be > 1"); }
+    DualRegev(const Device &d, uint32_t n_, uint32_t m_, uint32_t q_, double alpha_, uint64_t seed = fresh_seed())
+        : n(n_), m(m_), q(q_), alpha(alpha_), dev(&d), rng(d, seed) { if (q <= 1) throw Panic("modulus must be > 1"); default_noise(rng, n, alpha * q); }
     static DualRegev default_(const Device &d) { return DualRegev(d, 13, 154, 1427, 0.01); }
     static DualRegev new_from_n(const Device &d, uint32_t n) {   // dual_regev.rs:122-201 repeats regev.rs
         Regev r = Regev::new_from_n(d, n);
@@ -362,8 +414,8 @@ class DualRegev : public PKEncryptionScheme<DualRegev, MatZq, MatZ, MatZq> {
         std::vector<uint32_t> s = s_in ? *s_in : rng.uniform(3, n, q);
         std::vector<uint32_t> e = e_in ? *e_in : rng.noise(4, m + 1, q, noise_width());
         MatZq c(m + 1, 1, q);
-        DevKey k(*dev, pk);
-        dev->check(qf_vecmat_modq_host(dev->ctx(), k.get(), s.data(), c.e.data()));
+        qf_key *k = dev->cached_key(pk);
+        dev->check(qf_vecmat_modq_host(dev->ctx(), k, s.data(), c.e.data()));
         for (uint32_t j = 0; j <= m; j++) c.e[j] = (uint32_t)(((uint64_t)c.e[j] + e[j]) % q);
         c.set_entry(-1, 0, (uint64_t)c.get_entry(-1, 0) + (uint64_t)message_bit(message) * (q / 2));
         return c;
@@ -379,10 +431,10 @@ class DualRegev : public PKEncryptionScheme<DualRegev, MatZq, MatZ, MatZq> {
     DevBuf<uint32_t> enc_batch(const MatZq &pk, const std::vector<uint8_t> &msg_bits, const std::vector<uint32_t> &S, const std::vector<uint32_t> &E) {
         const uint64_t B = msg_bits.size();
         if (S.size() != B * n || E.size() != B * (m + 1)) throw Panic("mismatching randomness dimensions");
-        DevKey k(*dev, pk, true);
+        qf_key *k = dev->cached_key(pk, true);
         DevBuf<uint32_t> ds(*dev, S), de(*dev, E), out(*dev, B * (m + 1));
         DevBuf<uint8_t> dm(*dev, msg_bits);
-        dev->check(qf_matmul_modq_dev(dev->ctx(), k.get(), ds.get(), QF_X_U32, (size_t)n * 4, 0, B, de.get(), dm.get(), out.get()));
+        dev->check(qf_matmul_modq_dev(dev->ctx(), k, ds.get(), QF_X_U32, (size_t)n * 4, 0, B, de.get(), dm.get(), out.get()));
         return out;
     }
     Randomness &randomness() { return rng; }
@@ -401,8 +453,8 @@ class LPR : public PKEncryptionScheme<LPR, MatZq, MatZq, MatZq> {
   public:
     uint32_t n, q;
     double alpha;
-    LPR(const Device &d, uint32_t n_, uint32_t q_, double alpha_, uint64_t seed = MASTER_SEED)
-        : n(n_), q(q_), alpha(alpha_), dev(&d), rng(d, seed) { if (q <= 1) throw Panic("modulus must be > 1"); }
+    LPR(const Device &d, uint32_t n_, uint32_t q_, double alpha_, uint64_t seed = fresh_seed())
+        : n(n_), q(q_), alpha(alpha_), dev(&d), rng(d, seed) { if (q <= 1) throw Panic("modulus must be > 1"); default_noise(rng, n, alpha * q); }
     static LPR default_(const Device &d) { return LPR(d, 10, 983, 0.0072); }            // lpr.rs:306-312
     static LPR secure128(const Device &d) { return LPR(d, 500, 76859609, 0.000005); }   // lpr.rs:290-292
     static LPR new_from_n(const Device &d, uint32_t n) {                                // lpr.rs:113-191
@@ -451,8 +503,8 @@ class LPR : public PKEncryptionScheme<LPR, MatZq, MatZq, MatZq> {
         std::vector<uint32_t> r = r_in ? *r_in : rng.noise(3, n, q, W);
         std::vector<uint32_t> e = e_in ? *e_in : rng.noise(4, n + 1, q, W);
         MatZq c(n + 1, 1, q);
-        DevKey k(*dev, pk);
-        dev->check(qf_matvec_modq_host(dev->ctx(), k.get(), r.data(), c.e.data()));
+        qf_key *k = dev->cached_key(pk);
+        dev->check(qf_matvec_modq_host(dev->ctx(), k, r.data(), c.e.data()));
         for (uint32_t i = 0; i <= n; i++) c.e[i] = (uint32_t)(((uint64_t)c.e[i] + e[i]) % q);
         c.set_entry(-1, 0, (uint64_t)c.get_entry(-1, 0) + (uint64_t)message_bit(message) * (q / 2));
         return c;
@@ -466,10 +518,10 @@ class LPR : public PKEncryptionScheme<LPR, MatZq, MatZq, MatZq> {
         check_pk(pk);
         const uint64_t B = msg_bits.size();
         if (R.size() != B * n || E.size() != B * (n + 1)) throw Panic("mismatching randomness dimensions");
-        DevKey k(*dev, pk);
+        qf_key *k = dev->cached_key(pk);
         DevBuf<uint32_t> dr(*dev, R), de(*dev, E), out(*dev, B * (n + 1));
         DevBuf<uint8_t> dm(*dev, msg_bits);
-        dev->check(qf_matmul_modq_dev(dev->ctx(), k.get(), dr.get(), QF_X_U32, (size_t)n * 4, digits, B, de.get(), dm.get(), out.get()));
+        dev->check(qf_matmul_modq_dev(dev->ctx(), k, dr.get(), QF_X_U32, (size_t)n * 4, digits, B, de.get(), dm.get(), out.get()));
         return out;
     }
     std::vector<uint8_t> dec_batch(const MatZq &sk, const uint32_t *C_dev, uint64_t B) {
@@ -525,8 +577,8 @@ class RingLPR : public PKEncryptionScheme<RingLPR, RingPair, PolynomialRingZq, R
   public:
     uint32_t n, q;
     double alpha;
-    RingLPR(const Device &d, uint32_t n_, uint32_t q_, double alpha_, uint64_t seed = MASTER_SEED)
-        : n(n_), q(q_), alpha(alpha_), dev(&d), rng(d, seed), ring(d, n_, q_) {}
+    RingLPR(const Device &d, uint32_t n_, uint32_t q_, double alpha_, uint64_t seed = fresh_seed())
+        : n(n_), q(q_), alpha(alpha_), dev(&d), rng(d, seed), ring(d, n_, q_) { default_noise(rng, n, alpha * q); }
     static RingLPR default_(const Device &d) { return RingLPR(d, 16, 2399, 0.0039); }             // ring_lpr.rs:343-345
     static RingLPR secure128(const Device &d) { return RingLPR(d, 512, 92897729, 0.000005); }     // ring_lpr.rs:312-314
     void check_correctness() const {  // ring_lpr.rs:228-270
@@ -640,7 +692,7 @@ class RegevWithDiscreteGaussianRegularity
     : public PKEncryptionScheme<RegevWithDiscreteGaussianRegularity, GaussPublicKey, MatZq, GaussCipher> {
   public:
     GaussRegularityParams pp;
-    RegevWithDiscreteGaussianRegularity(const Device &d, uint32_t n, uint32_t m, uint32_t q, double r, double alpha, uint64_t seed = MASTER_SEED)
+    RegevWithDiscreteGaussianRegularity(const Device &d, uint32_t n, uint32_t m, uint32_t q, double r, double alpha, uint64_t seed = fresh_seed())
         : pp{n, m, q, r, alpha}, dev(&d), rng(d, seed) { if (q <= 1) throw Panic("modulus must be > 1"); }
     static RegevWithDiscreteGaussianRegularity default_(const Device &d) { return {d, 2, 16, 443, 4, 1.0 / 64}; }             // :329-338
     static RegevWithDiscreteGaussianRegularity secure128(const Device &d) { return {d, 350, 5248, 29892991, 12.357, 0.00009}; }  // :312-314
@@ -662,8 +714,8 @@ class RegevWithDiscreteGaussianRegularity
     GaussCipher enc(const GaussPublicKey &pk, int64_t message) {
         MatZq K = stacked(pk);
         std::vector<uint32_t> e = gauss(3, pp.m, pp.r), y(pp.n + 1);
-        DevKey k(*dev, K);
-        dev->check(qf_matvec_modq_host(dev->ctx(), k.get(), e.data(), y.data()));
+        qf_key *k = dev->cached_key(K);
+        dev->check(qf_matvec_modq_host(dev->ctx(), k, e.data(), y.data()));
         GaussCipher out{MatZq(pp.n, 1, pp.q), (uint32_t)(((uint64_t)y[pp.n] + (uint64_t)message_bit(message) * (pp.q / 2)) % pp.q)};
         std::copy(y.begin(), y.begin() + pp.n, out.vec.e.begin());
         return out;
@@ -683,9 +735,9 @@ class RegevWithDiscreteGaussianRegularity
         const uint64_t B = msg_bits.size();
         DevBuf<uint32_t> E(*dev, B * pp.m), out(*dev, B * (pp.n + 1));
         dev->check(qf_sample_discrete_gauss_dev(dev->ctx(), rng.seed(), 3, rng.take(3, B * pp.m), B * pp.m, pp.q, pp.n, pp.r, E.get()));
-        DevKey k(*dev, K);
+        qf_key *k = dev->cached_key(K);
         DevBuf<uint8_t> dm(*dev, msg_bits);
-        dev->check(qf_matmul_modq_dev(dev->ctx(), k.get(), E.get(), QF_X_U32, (size_t)pp.m * 4, 0, B, nullptr, dm.get(), out.get()));
+        dev->check(qf_matmul_modq_dev(dev->ctx(), k, E.get(), QF_X_U32, (size_t)pp.m * 4, 0, B, nullptr, dm.get(), out.get()));
         return out;
     }
     std::vector<uint8_t> dec_batch(const MatZq &sk, const uint32_t *C_dev, uint64_t B) {
@@ -717,7 +769,7 @@ class DualRegevWithDiscreteGaussianRegularity
     : public PKEncryptionScheme<DualRegevWithDiscreteGaussianRegularity, GaussPublicKey, MatZq, GaussCipher> {
   public:
     GaussRegularityParams pp;
-    DualRegevWithDiscreteGaussianRegularity(const Device &d, uint32_t n, uint32_t m, uint32_t q, double r, double alpha, uint64_t seed = MASTER_SEED)
+    DualRegevWithDiscreteGaussianRegularity(const Device &d, uint32_t n, uint32_t m, uint32_t q, double r, double alpha, uint64_t seed = fresh_seed())
         : pp{n, m, q, r, alpha}, dev(&d), rng(d, seed) { if (q <= 1) throw Panic("modulus must be > 1"); }
     static DualRegevWithDiscreteGaussianRegularity default_(const Device &d) { return {d, 2, 16, 443, 4, 1.0 / 64}; }
     static DualRegevWithDiscreteGaussianRegularity secure128(const Device &d) { return {d, 350, 5248, 29892991, 12.357, 0.00009}; }
@@ -737,8 +789,8 @@ class DualRegevWithDiscreteGaussianRegularity
     GaussCipher enc(const GaussPublicKey &pk, int64_t message) {
         MatZq K = joined(pk);
         std::vector<uint32_t> s = rng.uniform(3, pp.n, pp.q), x = gauss(4, pp.m + 1, pp.alpha * pp.q), y(pp.m + 1);
-        DevKey k(*dev, K);
-        dev->check(qf_vecmat_modq_host(dev->ctx(), k.get(), s.data(), y.data()));
+        qf_key *k = dev->cached_key(K);
+        dev->check(qf_vecmat_modq_host(dev->ctx(), k, s.data(), y.data()));
         for (uint32_t j = 0; j <= pp.m; j++) y[j] = (uint32_t)(((uint64_t)y[j] + x[j]) % pp.q);
         GaussCipher out{MatZq(pp.m, 1, pp.q), (uint32_t)(((uint64_t)y[pp.m] + (uint64_t)message_bit(message) * (pp.q / 2)) % pp.q)};
         std::copy(y.begin(), y.begin() + pp.m, out.vec.e.begin());
@@ -801,8 +853,8 @@ class PSFGPV {
         std::vector<uint32_t> x(m());
         for (uint32_t i = 0; i < m(); i++) x[i] = (uint32_t)(((sigma.e[i] % (int64_t)q) + q) % q);
         MatZq out(n, 1, q);
-        DevKey key(*dev, a);
-        dev->check(qf_matvec_modq_host(dev->ctx(), key.get(), x.data(), out.e.data()));
+        qf_key *key = dev->cached_key(a);
+        dev->check(qf_matvec_modq_host(dev->ctx(), key, x.data(), out.e.data()));
         return out;
     }
 
@@ -817,7 +869,7 @@ class SISHash {
   public:
     MatZq key;
     SISHash(const Device &d, MatZq k) : key(std::move(k)), dev(&d) {}
-    static SISHash gen(const Device &d, long n, uint32_t m, uint32_t q, uint64_t seed = MASTER_SEED) {  // sis.rs:79-93
+    static SISHash gen(const Device &d, long n, uint32_t m, uint32_t q, uint64_t seed = fresh_seed()) {  // sis.rs:79-93
         if (n < 1) throw MathError("n must be chosen bigger than 0.");
         Randomness rng(d, seed);
         MatZq A((uint32_t)n, m, q);
@@ -834,17 +886,17 @@ class SISHash {
         if (value.q != key.q) throw Panic("mismatching modulus");
         if (value.rows != key.cols) throw Panic("mismatching matrix dimensions");
         MatZq out(key.rows, 1, key.q);
-        DevKey k(*dev, key);
-        dev->check(qf_matvec_modq_host(dev->ctx(), k.get(), value.e.data(), out.e.data()));
+        qf_key *k = dev->cached_key(key);
+        dev->check(qf_matvec_modq_host(dev->ctx(), k, value.e.data(), out.e.data()));
         return out;
     }
     // B binary inputs (packed rows of bit_stride(m) bytes) on kernel (a): B x n digests on the device
     DevBuf<uint32_t> hash_batch_bits(const std::vector<uint8_t> &x_bits, uint64_t B) const {
         if (x_bits.size() != B * bit_stride(key.cols)) throw Panic("mismatching matrix dimensions");
-        DevKey k(*dev, key);
+        qf_key *k = dev->cached_key(key);
         DevBuf<uint8_t> dx(*dev, x_bits);
         DevBuf<uint32_t> out(*dev, B * key.rows);
-        dev->check(qf_matmul_modq_dev(dev->ctx(), k.get(), dx.get(), QF_X_BITS, bit_stride(key.cols), 1, B, nullptr, nullptr, out.get()));
+        dev->check(qf_matmul_modq_dev(dev->ctx(), k, dx.get(), QF_X_BITS, bit_stride(key.cols), 1, B, nullptr, nullptr, out.get()));
         return out;
     }
 

@@ -304,6 +304,71 @@ int main() {
         CHECK(m == want);
     });
 
+    run("device_key_cache", [&] {  // enc(&pk, ..) twice: the public key is uploaded and recoded once per distinct matrix
+        Regev r = Regev::new_from_n(dev, 20);
+        auto [pk, sk] = r.gen();
+        CHECK(r.dec(sk, r.enc(pk, 1)) == 1);
+        qf_key *k1 = dev.cached_key(pk);
+        const size_t count = dev.cached_keys();
+        for (int64_t msg : {1, 0, 1}) CHECK(r.dec(sk, r.enc(pk, msg)) == msg);
+        CHECK(dev.cached_keys() == count);                  // further enc calls upload nothing
+        CHECK(dev.cached_key(pk) == k1);                    // hit: same handle
+        MatZq pk2 = pk;
+        pk2.e[5] = (pk2.e[5] + 1) % pk2.q;                  // one entry differs -> a different key
+        CHECK(dev.cached_key(pk2) != k1);
+        CHECK(dev.cached_key(pk, true) != k1);              // the transposed upload is its own entry
+        std::vector<uint32_t> x = r.randomness().bits(3, r.m), ref(r.n + 1);
+        MatZq c = r.enc(pk2, 0, &x);                        // and it computes with ITS contents
+        qfo_matvec(pk2.e.data(), r.n + 1, r.m, r.q, x.data(), ref.data());
+        CHECK(c.e == ref);
+        for (int i = 0; i < 12; i++) {                      // eviction keeps at most 8 resident
+            MatZq t = pk; t.e[0] = (uint32_t)i % t.q; (void)dev.cached_key(t);
+        }
+        CHECK(dev.cached_keys() == 8);
+        CHECK(r.dec(sk, r.enc(pk, 1)) == 1);
+    });
+    run("key_replicate_two_contexts", [&] {  // the multi-GPU step (qf_key_replicate), here two contexts on one device
+        Device dev2(0);
+        Regev r = Regev::new_from_n(dev, 30);
+        auto [pk, sk] = r.gen();
+        qf_key *src = dev.cached_key(pk);
+        qf_ctx *ctxs[2] = {dev.ctx(), dev2.ctx()};
+        qf_key *rep[2] = {nullptr, nullptr};
+        CHECK(qf_key_replicate(ctxs, 2, src, rep) == QF_OK);
+        std::vector<uint32_t> x = r.randomness().bits(3, r.m), ref(r.n + 1), got(r.n + 1);
+        qfo_matvec(pk.e.data(), r.n + 1, r.m, r.q, x.data(), ref.data());
+        for (int i = 0; i < 2; i++) {
+            uint32_t rows = 0, cols = 0, qq = 0;
+            CHECK(rep[i] && qf_key_dims(rep[i], &rows, &cols, &qq) == QF_OK && rows == r.n + 1 && cols == r.m && qq == r.q);
+            CHECK(qf_matvec_modq_host(ctxs[i], rep[i], x.data(), got.data()) == QF_OK);
+            CHECK(got == ref);
+            // and the batched kernel on the replica: B = 40 encryptions against the oracle
+            const uint64_t B = 40;
+            std::vector<uint8_t> xb(B * bit_stride(r.m)), msg(B), bits;
+            qfo_sample_bits(MASTER_SEED, 3, 77, B, r.m, bit_stride(r.m), xb.data());
+            for (uint64_t b = 0; b < B; b++) msg[b] = (uint8_t)(b & 1);
+            Device &d = i ? dev2 : dev;
+            DevBuf<uint8_t> dx(d, xb), dm(d, msg);
+            DevBuf<uint32_t> out(d, B * (r.n + 1));
+            CHECK(qf_matmul_modq_dev(ctxs[i], rep[i], dx.get(), QF_X_BITS, bit_stride(r.m), 1, B, nullptr, dm.get(), out.get()) == QF_OK);
+            std::vector<uint32_t> want(B * (r.n + 1));
+            qfo_matmul_batch(pk.e.data(), r.n + 1, r.m, r.q, xb.data(), 0, bit_stride(r.m), B, nullptr, msg.data(), want.data());
+            CHECK(out.download() == want);
+        }
+        qf_key *none[1] = {nullptr};
+        CHECK(qf_key_replicate(nullptr, 2, src, rep + 0) == QF_ERR_ARG);
+        CHECK(qf_key_replicate(ctxs, 0, src, none) == QF_ERR_ARG);
+        for (qf_key *k : rep) qf_key_destroy(k);
+    });
+    run("default_seeds_are_fresh", [&] {  // two default-constructed schemes must not share secrets (advisor finding)
+        Regev a = Regev::default_(dev), b = Regev::default_(dev);
+        CHECK(a.randomness().seed() != b.randomness().seed());
+        auto ka = a.gen(), kb = b.gen();
+        CHECK(ka.second.e != kb.second.e);
+        Regev c(dev, 13, 154, 1427, 0.01, 42), d(dev, 13, 154, 1427, 0.01, 42);   // explicit seed: reproducible
+        CHECK(c.gen().second.e == d.gen().second.e);
+    });
+
     std::printf("%d checks, %d failures\n", checks, failures);
     return failures ? 1 : 0;
 }

@@ -134,7 +134,7 @@ def test_ring_lpr_n1024_ntt_friendly(ctx):
     # alpha is taken 64x below new_from_n(1024)'s value: at n=1024 the reference's own alpha
     # (ring_lpr.rs:183-191, "found out by experience" for small n) gives decryption noise of
     # about q/3 and does not round-trip; the arithmetic parity below does not depend on alpha.
-    s = RingLPR(1024, 1073479681, 1 / (5 * 32 * 1000 * 64), ctx=ctx)
+    s = RingLPR(1024, 1073479681, 1 / (5 * 32 * 1000 * 64), ctx=ctx, noise_model="irwin_hall")
     assert s.ring.uses_ntt
     pk, sk = s.gen()
     msgs = [0, 1, 2 ** 1024 - 1, 3 ** 600, 2 ** 1023 + 12345]
@@ -248,8 +248,9 @@ def test_cycle_with_discrete_gaussian_noise(ctx, make):
 
 
 def test_lpr_noise_digits_follow_the_model(ctx):
-    s = LPR.new_from_n(1024, ctx=ctx)
-    assert s.noise_digits == 2
+    s = LPR.new_from_n(1024, ctx=ctx, noise_model="irwin_hall")
+    assert s.rng.gauss is None and s.noise_digits == 2
+    assert LPR.new_from_n(1024, ctx=ctx).rng.gauss is not None      # the default is the reference's D_{Z, alpha*q}
     g = LPR.new_from_n(1024, ctx=ctx, noise_model="discrete_gauss")
     import math
     assert g.rng.noise_bound(g.noise_width) == math.ceil(float(g.alpha * g.q) * 10)
