@@ -60,6 +60,24 @@ def replicate_ring_key(ring, polys: Optional[np.ndarray], npoly: int, src: int =
     return ring.key(t)
 
 
+def regev_enc_shard(ctx, pk: Optional[np.ndarray], n: int, m: int, q: int, total: int, seed: int,
+                    x_stream: int = 3, msg_stream: int = 5):
+    """What ONE rank does for a batch of `total` Regev encryptions sharded over the process group --
+    the call sequence bench.py times: the key from rank 0 by one broadcast (recoded locally), this
+    rank's contiguous slice [lo, hi) of the global randomness and message streams drawn on its own
+    device, one batched product on kernel (a).  Returns (lo, hi, ciphertexts (hi-lo, n+1), message bits);
+    the outputs stay on the GPU that made them."""
+    from .device import X_BITS
+    rank, ws = world()
+    key = replicate_key(ctx, pk, n + 1, m, q)
+    lo, hi = shard_range(total, rank, ws)
+    B = hi - lo
+    xb = ctx.sample_bits(seed, x_stream, lo, B, m)
+    msg = (ctx.sample_uniform(seed, msg_stream, lo, B, 2) & 1).to(torch.uint8)
+    c = ctx.matmul(key, xb, X_BITS, B, msg=msg)
+    return lo, hi, c, msg
+
+
 def gather_counts(local_count: int) -> int:
     """Sum of per-rank item counts (bench bookkeeping only; not on the data path)."""
     rank, ws = world()
