@@ -95,6 +95,8 @@ int qf_ctx_create(int device, void *stream, qf_ctx **out) {
         delete ctx;
         return QF_ERR_DEVICE;
     }
+    // per-device address of the no-allocation entry point's scratch (qf_matvec.hip), this device current
+    if (qf_static_scratch_init(ctx) != QF_OK) { qf_ctx_destroy(ctx); return QF_ERR_DEVICE; }
     *out = ctx;
     return QF_OK;
 }
@@ -325,6 +327,12 @@ int qf_vecmat_modq_dev(qf_ctx *ctx, const qf_key *key, const uint32_t *x_dev, ui
     if (!ctx || !key || !x_dev || !y_dev) return QF_ERR_ARG;
     QF_BIND(ctx);
     return qf_launch_vecmat(ctx, key, x_dev, y_dev);
+}
+int qf_matvec_modq_static_dev(qf_ctx *ctx, const qf_key *key, const uint32_t *x_dev, uint32_t *y_dev) {
+    if (!ctx || !key || !x_dev || !y_dev) return QF_ERR_ARG;
+    if (key->device != ctx->device) return qf_fail(ctx, QF_ERR_ARG, "matvec: key lives on another device");
+    QF_BIND(ctx);
+    return qf_launch_matvec_static(ctx, key, x_dev, y_dev);
 }
 static int vec_host(qf_ctx *ctx, const qf_key *key, const uint32_t *x_host, uint32_t *y_host, bool trans) {
     if (!ctx || !key || !x_host || !y_host) return QF_ERR_ARG;

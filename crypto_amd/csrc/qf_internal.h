@@ -102,6 +102,8 @@ int qf_launch_transpose_u32(qf_ctx *ctx, const uint32_t *src, uint32_t rows, uin
 // qf_matvec.hip
 int qf_launch_matvec(qf_ctx *ctx, const qf_key *key, const uint32_t *x, uint32_t *y);
 int qf_launch_vecmat(qf_ctx *ctx, const qf_key *key, const uint32_t *x, uint32_t *y);
+int qf_launch_matvec_static(qf_ctx *ctx, const qf_key *key, const uint32_t *x, uint32_t *y);
+int qf_static_scratch_init(qf_ctx *ctx);   // resolves the per-device address of the static scratch array
 int qf_launch_dot_decode(qf_ctx *ctx, const uint32_t *w, uint32_t n, const QfMod &mod, const uint32_t *C,
                          uint64_t B, uint8_t *bits);
 // qf_sampler.hip

@@ -39,7 +39,7 @@ __device__ __forceinline__ uint32_t acc_finish(uint64_t lo, uint64_t hi, const Q
 //      moves between workgroups through device-scope atomics only, so nothing depends on
 //      placement, dispatch order or cache state (MI355X_MICROARCH.md, inter-workgroup visibility).
 // Scratch: one uint64 per padded row, zero before the launch (qf_ctx owns one, zeroed when it is
-// allocated).
+// allocated; the no-allocation entry point uses the file-scope array below).
 // ---------------------------------------------------------------------------------------------
 #define MVP_THREADS 256
 struct QfMvpArgs {
@@ -142,6 +142,25 @@ __global__ __launch_bounds__(MVP_THREADS) void qf_matvec_planes_kernel(QfMvpArgs
     }
 }
 
+// ---- the scratch of the no-allocation entry point (include/qfgpu.h: qf_matvec_modq_static_dev) ----
+// One uint64 per padded key row.  In HOST code the array's name is only a stand-in for the symbol:
+// its device address is looked up once per device (qf_static_scratch_init, called by qf_ctx_create
+// with that device current) and only that pointer is ever handed to a kernel or a memset.
+#define QF_STATIC_ROWS 32768
+static __device__ __align__(256) unsigned long long qf_static_scratch[QF_STATIC_ROWS];
+#define QF_MAX_DEVICES 64
+static unsigned long long *g_static_ptr[QF_MAX_DEVICES];
+
+int qf_static_scratch_init(qf_ctx *ctx) {
+    if (ctx->device < 0 || ctx->device >= QF_MAX_DEVICES) return qf_fail(ctx, QF_ERR_NOTSUP, "static scratch: device index out of range");
+    if (g_static_ptr[ctx->device]) return QF_OK;
+    unsigned long long *p = nullptr;
+    QF_HIP(ctx, hipGetSymbolAddress((void **)&p, HIP_SYMBOL(qf_static_scratch)));
+    if (!p) return qf_fail(ctx, QF_ERR_DEVICE, "static scratch: hipGetSymbolAddress returned null");
+    g_static_ptr[ctx->device] = p;
+    return QF_OK;
+}
+
 template <int L>
 static int mvp_launch(qf_ctx *ctx, const QfMvpArgs &a0, uint32_t ks) {
     // k-steps per wave: the smallest U that brings the grid to <= 768 workgroups.  Measured on the
@@ -199,6 +218,19 @@ int qf_launch_matvec(qf_ctx *ctx, const qf_key *key, const uint32_t *x, uint32_t
         QF_HIP(ctx, hipMemsetAsync(ctx->mv_acc, 0, need, ctx->stream));
     }
     return mvp_run(ctx, key, x, y, (unsigned long long *)ctx->mv_acc);
+}
+
+// No allocation anywhere on this path: the cross-workgroup sums live in qf_static_scratch (through
+// the per-device pointer).  The words it uses are cleared in front of every launch, so a call never
+// depends on what an earlier (possibly aborted) call left behind.
+int qf_launch_matvec_static(qf_ctx *ctx, const qf_key *key, const uint32_t *x, uint32_t *y) {
+    if (ctx->device < 0 || ctx->device >= QF_MAX_DEVICES || !g_static_ptr[ctx->device])
+        return qf_fail(ctx, QF_ERR_DEVICE, "matvec (static): scratch address of this device was not resolved");
+    if ((uint64_t)key->rb * 32 > QF_STATIC_ROWS)
+        return qf_fail(ctx, QF_ERR_NOTSUP, "matvec (static): key has more than 32768 (padded) rows");
+    unsigned long long *acc = g_static_ptr[ctx->device];
+    QF_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)key->rb * 32 * sizeof(unsigned long long), ctx->stream));
+    return mvp_run(ctx, key, x, y, acc);
 }
 
 // y^t = x^t*A : grid (column tiles of 1024, row chunks); thread owns 4 adjacent columns

@@ -123,6 +123,14 @@ int qf_vecmat_modq_host(qf_ctx *ctx, const qf_key *key, const uint32_t *x_host, 
 /* device-pointer forms (asynchronous) used by the benchmarks */
 int qf_matvec_modq_dev(qf_ctx *ctx, const qf_key *key, const uint32_t *x_dev, uint32_t *y_dev);
 int qf_vecmat_modq_dev(qf_ctx *ctx, const qf_key *key, const uint32_t *x_dev, uint32_t *y_dev);
+/* qf_matvec_modq_dev for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same
+ * result as qf_matvec_modq_dev; the cross-workgroup sums live in a file-scope device array of the
+ * library (256 KiB per GPU, held until the process ends) instead of context-owned scratch, and the
+ * call performs no hipMalloc/hipFree.  Limits: key rows (padded to a multiple of 32) <= 32768, else
+ * QF_ERR_NOTSUP.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two
+ * streams, two contexts, two processes' worth of threads) race -- serialise them. */
+int qf_matvec_modq_static_dev(qf_ctx *ctx, const qf_key *key, const uint32_t *x_dev, uint32_t *y_dev);
 
 /* Batched decryption:  r_b = <w, C[b][0..n)> + C[b][n] mod q ;
  *   bit_b = [dist(r_b,0) > dist(r_b, floor(q/2))]  (ring distance, ties -> 0)
