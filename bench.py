@@ -14,14 +14,14 @@ then every rank works on its own shard of the batch -- no collective on the data
 A step = one pass of the hot path over one batch: encrypt B messages (kernel a, int8-MFMA mod-q
 GEMM) and decrypt B ciphertexts (batched dot-decode).  Inputs are generated on the device by the
 seeded generator and are resident in HBM when the timed region starts.  The batch buffers rotate
-over R sets (x bits, messages, ciphertexts: 118 MB each, R = 4) and a step decrypts the set that was
+over R sets (x bits, messages, ciphertexts: 118 MB each, R = 6) and a step decrypts the set that was
 encrypted R-1 steps earlier, so the decode streams its 67 MB from HBM, not from the 256 MiB
 Infinity Cache where the GEMM just left them.
 
 The timed region (EXACTLY K steps between barrier + synchronize on both sides) contains no event
 records besides one at each end.  Per-kernel durations come from a second, untimed pass of the same
-K steps with a HIP event around every launch, on the launch stream; `roofline` divides the
-algorithmic work of the dominant kernel by that duration.  `cpu_baseline` is the C restatement of
+step loop in which sampled launches (every 4th step, the kernels taking turns) are bracketed by HIP
+events on the launch stream; `roofline` divides the algorithmic work of the dominant kernel by that duration.  `cpu_baseline` is the C restatement of
 the reference (oracle/, one message per call) on the host cores, on a bounded sample (rank 0, N=1).
 
 Prints ONE JSON line (rank 0)."""
@@ -52,7 +52,8 @@ def parse():
                     help="untimed: keep the GPU busy this long before the W warmup steps (the clock the chip "
                          "holds under load settles ~20 ms after idle)")
     ap.add_argument("--batch", type=int, default=65536, help="messages per GPU per step (headline)")
-    ap.add_argument("--sets", type=int, default=4, help="rotating batch buffer sets (headline)")
+    ap.add_argument("--sets", type=int, default=6, help="rotating batch buffer sets (headline): 6 x 67 MB of ciphertexts "
+                                                        "exceed the 256 MiB Infinity Cache also when the decode runs alone")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-ring", action="store_true", help="skip the secondary ring-polymul measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -232,20 +233,30 @@ class Run:
         el = time.perf_counter() - t0
         return self.max_over_ranks(el), e0.elapsed_time(e1)
 
-    def stamped(self, parts, steps):
-        """Untimed second pass: the same `steps` steps with a HIP event around every launch of every part.
-        parts: list of callables (one kernel launch each, in step order).  Returns mean ms per part."""
+    def sampled_ms(self, parts, steps, every=4):
+        """Untimed second pass of the SAME step loop (all parts of a step, in order, `steps` times -- the clock
+        the chip holds depends on the mix of kernels, so a kernel timed alone in a tight loop reads differently);
+        on every `every`-th step ONE part is bracketed by two HIP events on the launch stream, the parts taking
+        turns.  An event pair around every launch of every step would serialise the queue; sampled like this the
+        readings agree with the rocprofv3 kernel trace (profiles/r2).  Returns mean ms per part."""
         torch = self.torch
         n = len(parts)
-        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(n + 1)] for _ in range(steps)]
+        steps = max(steps, 16 * every * n)
+        samples = [[] for _ in range(n)]
         torch.cuda.synchronize()
         for k in range(steps):
-            ev[k][0].record()
+            pick = (k // every) % n if k % every == 0 else -1
             for j, p in enumerate(parts):
-                p()
-                ev[k][j + 1].record()
+                if j == pick:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    p()
+                    e1.record()
+                    samples[j].append((e0, e1))
+                else:
+                    p()
         torch.cuda.synchronize()
-        return [sum(ev[k][j].elapsed_time(ev[k][j + 1]) for k in range(steps)) / steps for j in range(n)]
+        return [sum(a.elapsed_time(b) for a, b in sm) / len(sm) for sm in samples]
 
     def emit(self, out):
         if self.rank == 0:
@@ -327,14 +338,14 @@ def headline(args):
     check_round_trip()
     value = world * B * args.steps / elapsed
 
-    # per-kernel durations: second, untimed pass of the same steps, an event around every launch
+    # per-kernel durations: second, untimed pass of the same step loop, sampled event pairs
     def p_enc():
         enc(state["k"] % NS)
 
     def p_dec():
         dec((state["k"] + 1) % NS)
         state["k"] += 1
-    gemm_ms, dec_ms = R_.stamped([p_enc, p_dec], args.steps)
+    gemm_ms, dec_ms = R_.sampled_ms([p_enc, p_dec], args.steps)
     achieved_tops = ops_per_enc * B / (gemm_ms * 1e-3) / 1e12
     dec_gbs = B * (n + 1) * 4 / (dec_ms * 1e-3) / 1e9
 
@@ -364,7 +375,7 @@ def headline(args):
                      "achieved": achieved_tops, "peak": INT8_PEAK_TOPS, "unit": "TOP/s", "frac": achieved_tops / INT8_PEAK_TOPS,
                      "traffic": pmc_traffic("regev", "qf_gemm_") if B == 65536 else None, "launch_ms": gemm_ms,
                      "note": "int8 multiply-accumulates counted as 2 ops; algorithmic ops = 2*La*Lb*(n+1)*m per encryption x B per launch; "
-                             "launch_ms = mean HIP-event duration of the GEMM over a second untimed pass of the same steps; "
+                             "launch_ms = mean of HIP-event pairs around sampled GEMM launches in a second, untimed pass of the same step loop; "
                              "traffic = HBM bytes per launch from the committed PMC passes (profiles/r2/regev/traffic.json)"},
         "decode": {"kernel": "qf_dot_decode_kernel", "bound": "hbm", "launch_ms": dec_ms, "achieved": dec_gbs, "peak": HBM_PEAK_GBS,
                    "unit": "GB/s", "frac": dec_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("regev", "qf_dot_decode") if B == 65536 else None,

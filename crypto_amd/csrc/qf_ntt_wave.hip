@@ -18,6 +18,11 @@
 // 3 multiplies + 6 adds/mins); otherwise every value is kept canonical.  All outputs are
 // canonical residues, bit-identical to the general kernel and the oracle.
 //
+// Global accesses are written (base + lane)[64 * r]: pointer + compile-time offset folds into the
+// instruction's immediate field.  Indexed as base[lane + 64 * r] with a 32-bit unsigned lane the sum
+// may wrap, so hipcc kept one address register per r alive across the whole item loop (16 VGPRs per
+// array, spilled in the FDH kernel).
+//
 // LDS: twiddle pairs (w, floor(w 2^32/q)) for both directions (16 KiB at n = 1024) + one
 // n-dword transpose buffer per wave; the transposes use an XOR swizzle of the low five address
 // bits (tools/ntt_swizzle_search.py) so that every ds_read_b32/ds_write_b32 is conflict free.
@@ -148,13 +153,15 @@ struct Wv {
         __builtin_amdgcn_wave_barrier();
     }
 
+    // twf_last: the twiddle table as the LAST phase sees it (the same LDS array; a caller may pass a
+    // pointer the compiler cannot see through to keep that phase's loads inside its loop)
     template <int P>
     static __device__ __forceinline__ void fwd_rec(uint32_t (&x)[R], uint32_t lane, uint32_t *buf, const uint2 *twf,
-                                                   const uint32_t *tw_g, uint32_t q) {
-        stages<P, true>(x, lane, twf, tw_g, q);
+                                                   const uint2 *twf_last, const uint32_t *tw_g, uint32_t q) {
+        stages<P, true>(x, lane, P + 1 < NP ? twf : twf_last, tw_g, q);
         if constexpr (P + 1 < NP) {
             transpose<P, P + 1>(x, lane, buf);
-            fwd_rec<P + 1>(x, lane, buf, twf, tw_g, q);
+            fwd_rec<P + 1>(x, lane, buf, twf, twf_last, tw_g, q);
         }
     }
     template <int P>
@@ -169,8 +176,8 @@ struct Wv {
     // x: natural order (idx = lane + 64 r), any value < 4q (lazy) / canonical -> NTT values in the
     // last phase's register order, in [0,4q) (lazy) / canonical
     static __device__ __forceinline__ void forward(uint32_t (&x)[R], uint32_t lane, uint32_t *buf, const uint2 *twf,
-                                                   const uint32_t *tw_g, uint32_t q) {
-        fwd_rec<0>(x, lane, buf, twf, tw_g, q);
+                                                   const uint32_t *tw_g, uint32_t q, const uint2 *twf_last = nullptr) {
+        fwd_rec<0>(x, lane, buf, twf, twf_last ? twf_last : twf, tw_g, q);
     }
     // x: last-phase order, [0,2q) (lazy) / canonical -> n * (inverse transform), natural order,
     // same ranges; the caller scales by n^-1
@@ -186,9 +193,37 @@ __device__ __forceinline__ uint32_t wv_red32(uint32_t x, uint32_t one_p, uint32_
     uint32_t r = x - __umulhi(x, one_p) * q;
     return CANON ? min(r, r - q) : r;
 }
+// any uint32 -> canonical residue.  q >= 2^30 (the non-lazy kernels): x < 2^32 <= 4q, two conditional
+// subtractions (4 simple operations instead of mul_hi + mul_lo + 3)
+template <bool LAZY>
+__device__ __forceinline__ uint32_t wv_canon(uint32_t x, uint32_t one_p, uint32_t q) {
+    if (LAZY) return wv_red32<true>(x, one_p, q);
+    x = min(x, x - 2 * q);
+    return min(x, x - q);
+}
+
+// waves per SIMD the register allocator must leave room for (n = 1024 only; measured choices,
+// tools/time_ring.py over tools/build_variant.sh builds)
+#ifndef QF_WV_W_POLYMUL
+#define QF_WV_W_POLYMUL 3
+#endif
+#ifndef QF_WV_W_FDH
+#define QF_WV_W_FDH 2
+#endif
+#ifndef QF_WV_W_ENC
+#define QF_WV_W_ENC 2
+#endif
+#ifndef QF_WV_FDH_HOIST
+#define QF_WV_FDH_HOIST 2   // 0: no twiddles kept across the transforms of a signature, 1: the middle phase's, 2: all
+#endif
+template <int LG, int MODE>
+constexpr int wv_min_waves() {
+    if (LG != 10) return 1;
+    return MODE == MODE_RLPR_ENC ? QF_WV_W_ENC : (MODE == MODE_FDH ? QF_WV_W_FDH : (MODE == MODE_POLYMUL ? QF_WV_W_POLYMUL : 4));
+}
 
 template <int LG, int MODE, bool LAZY>
-__global__ __launch_bounds__(WV_THREADS) void qf_ring_wave_kernel(QfRingArgs a) {
+__global__ __launch_bounds__(WV_THREADS, (wv_min_waves<LG, MODE>())) void qf_ring_wave_kernel(QfRingArgs a) {
     using W = Wv<LG, LAZY>;
     constexpr int N = W::N, R = W::R;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -206,19 +241,23 @@ __global__ __launch_bounds__(WV_THREADS) void qf_ring_wave_kernel(QfRingArgs a) 
     const uint32_t LI = Ph<LG, W::NP - 1>::lpart(lane);  // unused except for documentation of order
     (void)LI;
 
-    // canonical result of an inverse-transform output scaled by n^-1
-    auto finish = [&](uint32_t v) -> uint32_t {
-        uint32_t t = v * a.ninv - __umulhi(v, a.ninv_p) * q;
-        return min(t, t - q);
-    };
+    // canonical result of an inverse-transform output in the key-based modes: the prepared keys carry
+    // the factor n^-1 (MODE_FWD_ONLY), so nothing is left to scale -- [0,2q) (lazy) -> [0,q)
+    auto finish = [&](uint32_t v) -> uint32_t { return LAZY ? min(v, v - q) : v; };
     auto load_nat = [&](uint32_t(&x)[R], const uint32_t *src) {
 #pragma unroll
-        for (int r = 0; r < R; r++) x[r] = src[lane + 64 * r];
+        for (int r = 0; r < R; r++) x[r] = (src + lane)[64 * r];
+        // the first forward stage needs its "X" inputs below 4q (lazy) / everything canonical.  Lazy with
+        // q >= 2^29: any uint32 is below 8q, one conditional subtraction of 4q does it
+        if (LAZY && q >= (1u << 29)) {
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            // the first forward stage needs its "X" inputs below 4q (lazy) / everything canonical
-            if (LAZY) { if (r < R / 2) x[r] = wv_red32<false>(x[r], one_p, q); }
-            else x[r] = wv_red32<true>(x[r], one_p, q);
+            for (int r = 0; r < R / 2; r++) x[r] = min(x[r], x[r] - 4 * q);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if (LAZY) { if (r < R / 2) x[r] = wv_red32<false>(x[r], one_p, q); }
+                else x[r] = wv_canon<false>(x[r], one_p, q);
+            }
         }
     };
 
@@ -249,7 +288,7 @@ __global__ __launch_bounds__(WV_THREADS) void qf_ring_wave_kernel(QfRingArgs a) 
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const uint32_t t = xa[r] * a.ninv_m - __umulhi(xa[r], a.ninv_m_p) * q;
-                dst[lane + 64 * r] = min(t, t - q);
+                (dst + lane)[64 * r] = min(t, t - q);
             }
         } else if constexpr (MODE == MODE_FWD_ONLY) {
             // key preparation: interleaved (value, Shoup companion) pairs in last-phase register order
@@ -259,9 +298,10 @@ __global__ __launch_bounds__(WV_THREADS) void qf_ring_wave_kernel(QfRingArgs a) 
             uint2 *dst = (uint2 *)a.out0 + item * N;
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                uint32_t v = x[r];
-                if (LAZY) { v = min(v, v - q2); v = min(v, v - q); }
-                dst[lane + 64 * r] = make_uint2(v, (uint32_t)((((uint64_t)v) << 32) / q));
+                // n^-1 goes into the key: the key-based modes then need no scaling after their inverse transforms
+                uint32_t v = x[r] * a.ninv - __umulhi(x[r], a.ninv_p) * q;
+                v = min(v, v - q);
+                (dst + lane)[64 * r] = make_uint2(v, (uint32_t)((((uint64_t)v) << 32) / q));
             }
         } else if constexpr (MODE == MODE_RLPR_ENC) {
             // the noise polynomials are fetched ahead of the transforms that precede their use
@@ -270,7 +310,7 @@ __global__ __launch_bounds__(WV_THREADS) void qf_ring_wave_kernel(QfRingArgs a) 
             uint32_t xr[R], t[R], e1[R], e2[R];
             const uint32_t *n1 = a.in1 + item * N, *n2 = a.in2 + item * N;
 #pragma unroll
-            for (int r = 0; r < R; r++) e1[r] = n1[lane + 64 * r];
+            for (int r = 0; r < R; r++) e1[r] = (n1 + lane)[64 * r];
             load_nat(xr, a.in0 + item * N);
             // message bits: word j of the row holds coefficients 32j..32j+31
             const uint32_t *mrow = (const uint32_t *)(a.mu + item * (uint64_t)(N / 8));
@@ -279,54 +319,54 @@ __global__ __launch_bounds__(WV_THREADS) void qf_ring_wave_kernel(QfRingArgs a) 
             const uint2 *kha = (const uint2 *)a.key, *khb = (const uint2 *)a.key + N;
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                uint2 k2 = kha[lane + 64 * r];
+                uint2 k2 = (kha + lane)[64 * r];
                 uint32_t v = xr[r] * k2.x - __umulhi(xr[r], k2.y) * q;  // [0,2q)
                 t[r] = LAZY ? v : min(v, v - q);
             }
             constexpr bool PRE2 = R <= 16;  // n = 2048: 128 data registers would spill
             if (PRE2) {
 #pragma unroll
-                for (int r = 0; r < R; r++) e2[r] = n2[lane + 64 * r];
+                for (int r = 0; r < R; r++) e2[r] = (n2 + lane)[64 * r];
             }
             W::inverse(t, lane, buf, twi, twg_i, q);
             uint32_t *du = a.out0 + item * N, *dv = a.out1 + item * N;
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                uint32_t val = finish(t[r]) + wv_red32<true>(e1[r], one_p, q);
-                du[lane + 64 * r] = min(val, val - q);
+                uint32_t val = finish(t[r]) + wv_canon<LAZY>(e1[r], one_p, q);
+                (du + lane)[64 * r] = min(val, val - q);
             }
             if (!PRE2) {
 #pragma unroll
-                for (int r = 0; r < R; r++) e2[r] = n2[lane + 64 * r];
+                for (int r = 0; r < R; r++) e2[r] = (n2 + lane)[64 * r];
             }
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                uint2 k2 = khb[lane + 64 * r];
+                uint2 k2 = (khb + lane)[64 * r];
                 uint32_t v = xr[r] * k2.x - __umulhi(xr[r], k2.y) * q;
                 t[r] = LAZY ? v : min(v, v - q);
             }
             W::inverse(t, lane, buf, twi, twg_i, q);
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                uint32_t val = finish(t[r]) + wv_red32<true>(e2[r], one_p, q);
+                uint32_t val = finish(t[r]) + wv_canon<LAZY>(e2[r], one_p, q);
                 val = min(val, val - q);
                 uint32_t wlo = __builtin_amdgcn_readlane(mword, (2 * r) % (N / 32));
                 uint32_t whi = __builtin_amdgcn_readlane(mword, (2 * r + 1) % (N / 32));
                 uint32_t wsel = lane < 32 ? wlo : whi;
                 val += ((wsel >> (lane & 31)) & 1u) ? a.mod.qhalf : 0u;
-                dv[lane + 64 * r] = min(val, val - q);
+                (dv + lane)[64 * r] = min(val, val - q);
             }
         } else if constexpr (MODE == MODE_RLPR_DEC) {
             uint32_t x[R], vraw[R];
             const uint32_t *vv = a.in1 + item * N;
 #pragma unroll
-            for (int r = 0; r < R; r++) vraw[r] = vv[lane + 64 * r];  // fetched ahead of the transforms
+            for (int r = 0; r < R; r++) vraw[r] = (vv + lane)[64 * r];  // fetched ahead of the transforms
             load_nat(x, a.in0 + item * N);
             W::forward(x, lane, buf, twf, twg_f, q);
             const uint2 *kh = (const uint2 *)a.key;
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                uint2 k2 = kh[lane + 64 * r];
+                uint2 k2 = (kh + lane)[64 * r];
                 uint32_t v = x[r] * k2.x - __umulhi(x[r], k2.y) * q;
                 x[r] = LAZY ? v : min(v, v - q);
             }
@@ -335,7 +375,7 @@ __global__ __launch_bounds__(WV_THREADS) void qf_ring_wave_kernel(QfRingArgs a) 
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 uint32_t su = finish(x[r]);
-                uint32_t w = qf_submod(wv_red32<true>(vraw[r], one_p, q), su, q);
+                uint32_t w = qf_submod(wv_canon<LAZY>(vraw[r], one_p, q), su, q);
                 bool bit = qf_ring_dist(w, a.mod.qhalf, q) < qf_ring_dist(w, 0, q);
                 uint64_t m = __ballot(bit);  // coefficients 64r .. 64r+63
                 if (lane == (uint32_t)(2 * r)) myword = (uint32_t)m;
@@ -352,23 +392,32 @@ __global__ __launch_bounds__(WV_THREADS) void qf_ring_wave_kernel(QfRingArgs a) 
             uint64_t nlo = 0, nhi = 0;  // exact sum of squares, split so nothing overflows
 #pragma unroll 1
             for (uint32_t j = 0; j < a.npoly; j++) {
+                // hipcc hoists loop-invariant twiddle loads out of this loop: wanted for the middle phase (its
+                // 15 (w, w') pairs stay in registers across the 32 transforms of a signature), but with the
+                // last phase's 12 pairs too the kernel needs more than 256 VGPRs and drops to one wave per
+                // SIMD.  The last phase therefore reads through a pointer the compiler cannot see through.
+                const uint2 *twf_j = twf;
+                if (QF_WV_FDH_HOIST < 2) asm volatile("" : "+v"(twf_j));
                 const int32_t *sj = sig + (size_t)j * N;
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    int32_t sv = sj[lane + 64 * r];
+                    int32_t sv = (sj + lane)[64 * r];
                     uint64_t sq = (uint64_t)((int64_t)sv * (int64_t)sv);
                     nlo += (uint32_t)sq; nhi += sq >> 32;
                     // off32 = smallest multiple of q >= 2^31 lies in [2^31, 2^31 + q): added to NEGATIVE
                     // coefficients only (sv + off32 in [0, off32)); a non-negative sv is its own
                     // 32-bit representative (adding off32 to it could wrap past 2^32)
-                    const uint32_t sr = sv < 0 ? (uint32_t)sv + a.off32 : (uint32_t)sv;
-                    x[r] = LAZY ? wv_red32<false>(sr, one_p, q) : wv_red32<true>(sr, one_p, q);
+                    const uint32_t sr = (uint32_t)sv + (a.off32 & (uint32_t)(sv >> 31));
+                    x[r] = LAZY ? wv_red32<false>(sr, one_p, q) : wv_canon<false>(sr, one_p, q);
                 }
-                W::forward(x, lane, buf, twf, twg_f, q);
+                W::forward(x, lane, buf, QF_WV_FDH_HOIST == 0 ? twf_j : twf, twg_f, q, twf_j);
+                // the 16 key pairs are fetched AFTER the transform (they are L2-resident; fetched ahead
+                // they would hold 32 more registers through it)
+                asm volatile("" ::: "memory");
                 const uint2 *kh = (const uint2 *)a.key + (size_t)j * N;
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    uint2 k2 = kh[lane + 64 * r];
+                    uint2 k2 = (kh + lane)[64 * r];
                     uint32_t v = x[r] * k2.x - __umulhi(x[r], k2.y) * q;  // [0,2q)
                     if (LAZY) { uint32_t s = acc[r] + v; acc[r] = min(s, s - q2); }
                     else { v = min(v, v - q); uint32_t s = acc[r] + v; acc[r] = min(s, s - q); }
@@ -379,9 +428,13 @@ __global__ __launch_bounds__(WV_THREADS) void qf_ring_wave_kernel(QfRingArgs a) 
             uint32_t neq = 0;
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                uint32_t tv = finish(acc[r]);
-                if (a.out0) a.out0[item * N + lane + 64 * r] = tv;
-                neq |= (tv != wv_red32<true>(urow[lane + 64 * r], one_p, q));
+                acc[r] = finish(acc[r]);
+                neq |= (acc[r] != wv_canon<LAZY>((urow + lane)[64 * r], one_p, q));
+            }
+            if (a.out0) {   // one uniform branch around all the stores (not one per coefficient)
+                uint32_t *trow = a.out0 + item * N + lane;
+#pragma unroll
+                for (int r = 0; r < R; r++) trow[64 * r] = acc[r];
             }
             nlo = qf_wave_sum_u64(nlo); nhi = qf_wave_sum_u64(nhi);
             const uint64_t anyneq = __ballot(neq != 0);

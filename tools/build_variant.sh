@@ -7,6 +7,7 @@ tmp=$(mktemp -d)
 for f in qf_api qf_gemm qf_matvec qf_ntt qf_ntt_wave qf_sampler qf_sha256; do
   flags=""
   [ $f = qf_gemm ] && flags="$*"
+  [ $f = qf_ntt_wave ] && flags="$*"
   rem=""
   [ $f = qf_gemm ] && rem="-Rpass-analysis=kernel-resource-usage"
   /opt/rocm/bin/hipcc $flags $rem -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -c $root/crypto_amd/csrc/$f.hip -o $tmp/$f.o 2> $tmp/$f.remarks &
