@@ -56,6 +56,8 @@ def parse():
                                                         "exceed the 256 MiB Infinity Cache also when the decode runs alone")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-ring", action="store_true", help="skip the secondary ring-polymul measurement")
+    ap.add_argument("--no-check", action="store_true", help="skip the small property-check launches (profile runs: keeps "
+                                                             "the kernel-trace averages to full-size launches only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--workload", default="regev", choices=WORKLOADS,
                     help="regev = the headline (BASELINE config 2); the others are the remaining configs, "
@@ -497,7 +499,7 @@ def other_workloads(args):
                                     "value": B2 / (ms2 * 1e-3), "unit": "hashes/s", "batch_per_gpu": B2, "call_ms": ms2,
                                     "achieved_tops": 2 * 9 * n * m * B2 / (ms2 * 1e-3) / 1e12}
         # linearity property at full size: H(x) + H(y) == H(x xor y) + 2*H(x and y)  (mod q)
-        if rank == 0:
+        if rank == 0 and not args.no_check:
             k = min(B, 4096)
             x, y = xb[:k], ctx.sample_bits(SEED, 7, 0, k, m)
             hx = ctx.matmul(key, x, X_BITS, k).to(torch.int64)

@@ -40,7 +40,44 @@ reference_kats = {
         "A": [[2, 6, 2, 5, 3, 0, 1, 1, 1, 6, 5, 0, 6], [6, 0, 3, 1, 5, 6, 2, 7, 0, 3, 7, 7, 0]],
         "R": [[0, 1, 0, 1, 1, 0], [-1, 1, 0, 0, 0, -1], [-1, 0, -1, -1, -1, 0], [-1, 1, 0, 0, 0, 1],
               [-1, -1, 0, 1, 0, 1], [-1, 0, 0, -1, 0, 1], [0, -1, 0, 0, 0, 0]],
-        "G": [[1, 2, 4, 0, 0, 0], [0, 0, 0, 1, 2, 4]]},
+        "G": [[1, 2, 4, 0, 0, 0], [0, 0, 0, 1, 2, 4]],
+        # working_sa_r_identity, short_basis_classical.rs:339-356: gen_sa_r(params, tag = I, A) = [0 | I ; S' | W]
+        # with G*W = -A*[I_7 | 0] mod 8 (compute_w :114-119) -- the reference's literal 13 x 13 output
+        "sa_r_identity": [
+            [0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0],
+            [0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0], [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0], [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0],
+            [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1], [0, 0, 0, 0, 0, 2, 0, 0, 0, 1, 1, 0, 1], [0, 0, 0, 0, 2, -1, 1, 1, 1, 1, 0, 0, 1],
+            [0, 0, 0, 2, -1, 0, 1, 0, 1, 0, 1, 0, 1], [0, 0, 2, 0, 0, 0, 0, 0, 1, 1, 1, 0, 0], [0, 2, -1, 0, 0, 0, 1, 0, 0, 1, 1, 1, 1],
+            [2, -1, 0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 1]]},
+    # working_sa_r, short_basis_ring.rs:404-439: gen_sa_r for the fixed ring trapdoor above (n = 4, q = 16, k = 4),
+    # reduced by X^4 + 1 and coefficient-embedded (24 x 24; row 4*i + c = coefficient c of polynomial row i).  Columns
+    # 16.. hold pd (x) [I_2 ; w]: w = base-2 digits of (-1)*a_0 and (-1)*a_1 in R_16 (compute_w :128-139), then
+    # every X^s * w reduced by X^4 + 1; columns 0..15 hold pd (x) S'' (monomials 2*X^s and -X^s)
+    "ring_sa_r_n4_q16": {"n": 4, "q": 16, "k": 4, "matrix": [
+        [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0],
+        [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0],
+        [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0],
+        [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0],
+        [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0],
+        [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0],
+        [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0],
+        [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1],
+        [0, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0],
+        [0, 0, 0, 0, 0, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0],
+        [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0],
+        [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 0, 0, 0, 0, 0, 0, 1, 0],
+        [0, 0, 2, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0],
+        [0, 0, 0, 0, 0, 0, 2, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 0],
+        [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, -1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 0, 0],
+        [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, -1, 0, 0, 0, 0, 0, 0, 1, 1],
+        [0, 2, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 0, -1, 0, 0, 0, 0],
+        [0, 0, 0, 0, 0, 2, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 0, -1, 0, 0],
+        [0, 0, 0, 0, 0, 0, 0, 0, 0, 2, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 0, -1],
+        [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, -1, 0, 0, 1, 0, 0, 0, 0, 1, 1],
+        [2, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 0, -1, 0, -1],
+        [0, 0, 0, 0, 2, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 0, 0, 0, -1],
+        [0, 0, 0, 0, 0, 0, 0, 0, 2, -1, 0, 0, 0, 0, 0, 0, 0, 1, 0, 1, 1, 1, 0, 0],
+        [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, -1, 0, 0, 0, 0, 0, 1, 0, 1, 1, 1]]},
     "sha256": {"Hello World!": "7f83b1657ff1fc53b92dc18148a1d65dfc2d4b1fa3d677284addd200126d9069",
                "qfall": "eb6ed1369a670050bd04b24036e8c29144b0f6b10166dc9c8b4987a6026c715f"},
     "hash_to_zq": [["Hello World!", 7, 2], ["Hello World!", 256, 150], ["qfall", 16, 12]],

@@ -325,6 +325,34 @@ def test_fixed_ring_trapdoor_kat_on_device(ctx):
     assert ctx.to_host_u8(ok).tolist() == [1, 1, 1, 1]
 
 
+def test_reference_gen_sa_r_outputs_on_device(ctx):
+    """The two literal outputs the reference's tests hold for this path (working_sa_r, short_basis_ring.rs:
+    404-439; working_sa_r_identity, short_basis_classical.rs:339-356): every ring product of the first through
+    the product kernel, the two Z_q matrix products of the second through kernels (a) and (c)."""
+    import json, os
+    from test_oracle_golden import ring_sa_r_products
+    kats = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))
+    n, q, cases = ring_sa_r_products(kats)
+    a = np.array([c[0] for c in cases], np.uint32)
+    b = np.array([c[1] for c in cases], np.uint32)
+    want = np.array([c[2] for c in cases], np.uint32)
+    got = ctx.to_host_u32(ctx.ring(n, q).polymul(ctx.to_dev_u32(a), ctx.to_dev_u32(b)))
+    assert np.array_equal(got, want)
+    k = kats["classical_trapdoor_n2_q8"]
+    q, A, G = k["q"], np.array(k["A"], np.uint32), np.array(k["G"], np.uint32)
+    M = np.array(k["sa_r_identity"], np.int64)
+    W = M[7:, 6:]
+    E = -np.vstack([np.eye(7, dtype=np.int64), np.zeros((6, 7), np.int64)])
+    kG, kA = ctx.key_upload(G, q), ctx.key_upload(A, q)
+    lhs = ctx.to_host_u32(ctx.matmul(kG, ctx.to_dev_i32(np.ascontiguousarray(W.T)), X_I32, 7))
+    rhs = ctx.to_host_u32(ctx.matmul(kA, ctx.to_dev_i32(np.ascontiguousarray(E.T)), X_I32, 7))
+    assert np.array_equal(lhs, rhs)
+    assert np.array_equal(rhs.T, (-A[:, :7].astype(np.int64)) % q)
+    for j in range(7):
+        assert ctx.matvec(kG, (W[:, j] % q).astype(np.uint32)).tolist() == rhs[j].tolist()
+        assert ctx.matvec(kA, (E[:, j] % q).astype(np.uint32)).tolist() == rhs[j].tolist()
+
+
 @pytest.mark.parametrize("bits", [False, True])
 def test_matmul_chunked_raster_order(ctx, monkeypatch, bits):
     """qf_gemm_raster: chunks of message tiles run through every column tile; 19 message tiles in

@@ -156,3 +156,18 @@ def test_gaussian_regularity_new_from_n_reports_empty_ranges():
     for n in (30, 37):
         p = R.new_from_n(n, ctx=object())
         p.check_correctness(); p.check_security()
+
+
+def test_asm_window_checker_flags_a_touched_destination(tmp_path):
+    """crypto_amd/csrc/check_asm_window.py (build guard of qf_gemm's inline-asm operand loads): a compiler
+    instruction that names a load's destination register before the matching asm wait fails the build."""
+    import subprocess, sys
+    tool = os.path.join(ROOT, "crypto_amd", "csrc", "check_asm_window.py")
+    body = ("_Z7qf_gemmv: ; @_Z7qf_gemmv\n\t;;#ASMSTART\n\tglobal_load_dwordx4 v[10:13], v[2:3], off\n\t;;#ASMEND\n"
+            "%s\t;;#ASMSTART\n\ts_waitcnt vmcnt(0)\n\t;;#ASMEND\n\tv_mov_b32_e32 v5, v11\n\ts_endpgm\n.Lfunc_end0:\n")
+    good, bad = tmp_path / "good.s", tmp_path / "bad.s"
+    good.write_text(body % "\tv_add_u32_e32 v4, v2, v3\n")
+    bad.write_text(body % "\tv_accvgpr_write_b32 a0, v12\n")
+    assert subprocess.run([sys.executable, tool, str(good), "qf_gemm"], capture_output=True).returncode == 0
+    r = subprocess.run([sys.executable, tool, str(bad), "qf_gemm"], capture_output=True, text=True)
+    assert r.returncode != 0 and "v[12]" in r.stdout

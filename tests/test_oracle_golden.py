@@ -190,6 +190,67 @@ def test_fixed_classical_trapdoor_kat():
     assert np.array_equal(co.matmul_batch(A, q, cols, co.X_I32, 6), G.T)
 
 
+def ring_sa_r_products(kats):
+    """The ring products the reference's literal gen_sa_r output pins (short_basis_ring.rs:404-439; fixture
+    ring_sa_r_n4_q16): (factor a, factor b, a*b mod (X^4+1, 16)) triples read off the 24 x 24 matrix.
+      * every X^s * w_j[b] for the base-2 digit polynomials w of -a_0, -a_1 (columns 16..23),
+      * every X^s * (entry of S'') for the monomials 2 and -1 (columns 0..15),
+      * (-1) * a_j itself, recomposed from its digits: sum_b 2^b w_j[b] = -a_j  (compute_w :128-139)."""
+    k, t = kats["ring_sa_r_n4_q16"], kats["ring_trapdoor_n4_q16"]
+    n, q, kk = k["n"], k["q"], k["k"]
+    M = np.array(k["matrix"], np.int64)
+    poly = lambda i, col: M[n * i:n * i + n, col]           # coefficients of polynomial row i in column col
+    mono = lambda s: np.eye(n, dtype=np.int64)[s]
+    out = []
+    for j in range(2):
+        digits = [poly(2 + b, 16 + j) for b in range(kk)]
+        for b in range(kk):
+            for s in range(n):
+                out.append((digits[b] % q, mono(s), poly(2 + b, 16 + 2 * s + j) % q))
+        a_j = np.array(list(t["a"][j]) + [0] * (n - len(t["a"][j])), np.int64)
+        neg = sum((1 << b) * digits[b] for b in range(kk)) % q
+        out.append((a_j % q, (q - 1) * mono(0), neg))        # (-1) * a_j in R_16
+    for s in range(n):
+        for tcol in range(kk):
+            for i in range(kk):
+                out.append((poly(2 + i, tcol) % q, mono(s), poly(2 + i, kk * s + tcol) % q))
+    return n, q, out
+
+
+def test_reference_gen_sa_r_ring_output():
+    """working_sa_r (short_basis_ring.rs:404-439): the literal matrix the reference prints -- every ring
+    product it contains, through both oracles."""
+    n, q, cases = ring_sa_r_products(KATS)
+    assert len(cases) == 2 * (4 * 4 + 1) + 4 * 4 * 4
+    a = np.array([c[0] for c in cases], np.uint32)
+    b = np.array([c[1] for c in cases], np.uint32)
+    want = np.array([c[2] for c in cases], np.uint32)
+    assert np.array_equal(co.polymul_batch(a, b, q), want)
+    for x, y, w in cases:
+        assert po.polymul_negacyclic([int(v) for v in x], [int(v) for v in y], q) == [int(v) for v in w]
+    assert any((w != 0).any() and (w > 8).any() for _, _, w in cases)      # the -1 entries are really exercised
+
+
+def test_reference_gen_sa_r_classical_output():
+    """working_sa_r_identity (short_basis_classical.rs:339-356): the literal 13 x 13 matrix [0 | I ; S' | W];
+    its W block satisfies G*W = -A*[I_7 | 0] mod 8 (compute_w :114-119) -- two Z_q matrix products."""
+    k = KATS["classical_trapdoor_n2_q8"]
+    q, A, G = k["q"], np.array(k["A"], np.uint32), np.array(k["G"], np.uint32)
+    M = np.array(k["sa_r_identity"], np.int64)
+    assert np.array_equal(M[:7, 6:], np.eye(7, dtype=np.int64)) and not M[:7, :6].any()
+    W = M[7:, 6:]                                                        # 6 x 7
+    E = -np.vstack([np.eye(7, dtype=np.int64), np.zeros((6, 7), np.int64)])   # -[I_7 ; 0]: 13 x 7
+    lhs = co.matmul_batch(G, q, np.ascontiguousarray(W.T).astype(np.int32), co.X_I32, 7)   # rows: (G*W_j)^t
+    rhs = co.matmul_batch(A, q, np.ascontiguousarray(E.T).astype(np.int32), co.X_I32, 7)   # rows: (-A e_j)^t
+    assert np.array_equal(lhs, rhs)
+    assert np.array_equal(rhs.T, (-A[:, :7].astype(np.int64)) % q)
+    for j in range(7):
+        assert po.matvec(G.tolist(), [int(v) % q for v in W[:, j]], q) == [int(v) for v in rhs[j]]
+    # S' = I_2 (x) S_k with G*S' = 0 mod 8 (the gadget's own short basis, compute_s :89-111)
+    S = M[7:, :6]
+    assert not co.matmul_batch(G, q, np.ascontiguousarray(S.T).astype(np.int32), co.X_I32, 6).any()
+
+
 def test_oracle_discrete_gauss_distribution():
     """The oracle's inversion sampler draws D_{Z,s}: support, mean, variance s^2/(2 pi).  (Parity with the
     reference's sampler is distributional only -- its RNG is unseeded, qfall-math is not in the tree.)"""

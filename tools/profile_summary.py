@@ -38,6 +38,32 @@ for k in sorted(dur, key=lambda k: -sum(dur[k])):
                  "min_us": round(min(v), 2), "max_us": round(max(v), 2),
                  "fetch_bytes_per_launch_x2": round(2 * 1024 * sum(tail(fe)) / max(1, len(tail(fe)))) if fe else None,
                  "write_bytes_per_launch": round(1024 * sum(tail(wr)) / max(1, len(tail(wr)))) if wr else None})
+# matrix-pipe pass (GEMM workloads): MFMA busy share and LDS conflict share per kernel
+f = find("pmc_mfma/**/*counter_collection.csv")
+if f:
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    tmp = collections.defaultdict(dict)
+    for r in csv.DictReader(open(f)):
+        tmp[(r["Dispatch_Id"], short(r["Kernel_Name"]))][r["Counter_Name"]] = float(r["Counter_Value"])
+    for (_, k), m in tmp.items():
+        for n, v in m.items():
+            per[k][n].append(v)
+    mf = {}
+    for k, c in per.items():
+        m = {n: sum(v[len(v) // 2:]) / max(1, len(v[len(v) // 2:])) for n, v in c.items()}
+        cyc = m.get("GRBM_GUI_ACTIVE", 0) / 8          # the counter sums the 8 XCDs
+        if not cyc or not m.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+            continue
+        mf[k] = {"launches": len(c["GRBM_GUI_ACTIVE"]), "cycles_per_launch": round(cyc),
+                 "mfma_busy_cycles": round(m["SQ_VALU_MFMA_BUSY_CYCLES"]),
+                 # SQ_VALU_MFMA_BUSY_CYCLES counts cycles a SIMD's matrix pipe is busy, summed over the 1,024 SIMDs
+                 "mfma_busy_share_of_simd_cycles": round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc), 4),
+                 "insts_lds": round(m.get("SQ_INSTS_LDS", 0)), "lds_bank_conflict_cycles": round(m.get("SQ_LDS_BANK_CONFLICT", 0)),
+                 "mfma_mops_i8": round(m.get("SQ_INSTS_VALU_MFMA_MOPS_I8", 0)), "wave_cycles": round(m.get("SQ_WAVE_CYCLES", 0)),
+                 "effective_clock_ghz_if_launch_ms_known": None}
+    json.dump(mf, open(os.path.join(d, "mfma_util.json"), "w"), indent=1)
+    for k, v in mf.items():
+        print("MFMA", k, v)
 with open(os.path.join(d, "kernel_stats.csv"), "w", newline="") as fo:
     w = csv.DictWriter(fo, fieldnames=list(rows[0].keys()) if rows else ["kernel"])
     w.writeheader(); w.writerows(rows)
