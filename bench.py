@@ -239,15 +239,16 @@ class Run:
         """Untimed second pass of the SAME step loop (all parts of a step, in order, `steps` times -- the clock
         the chip holds depends on the mix of kernels, so a kernel timed alone in a tight loop reads differently);
         on every `every`-th step ONE part is bracketed by two HIP events on the launch stream, the parts taking
-        turns.  An event pair around every launch of every step would serialise the queue; sampled like this the
-        readings agree with the rocprofv3 kernel trace (profiles/r2).  Returns mean ms per part."""
+        turns, and in one more turn the two events are recorded back to back with nothing between them: that
+        reading is what the bracket itself costs (the command processor handles two markers around the launch),
+        and it is subtracted.  Returns (mean ms per part, event-pair overhead ms)."""
         torch = self.torch
         n = len(parts)
-        steps = max(steps, 16 * every * n)
-        samples = [[] for _ in range(n)]
+        steps = max(steps, 16 * every * (n + 1))
+        samples = [[] for _ in range(n + 1)]
         torch.cuda.synchronize()
         for k in range(steps):
-            pick = (k // every) % n if k % every == 0 else -1
+            pick = (k // every) % (n + 1) if k % every == 0 else -1
             for j, p in enumerate(parts):
                 if j == pick:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -257,8 +258,14 @@ class Run:
                     samples[j].append((e0, e1))
                 else:
                     p()
+            if pick == n:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                e1.record()
+                samples[n].append((e0, e1))
         torch.cuda.synchronize()
-        return [sum(a.elapsed_time(b) for a, b in sm) / len(sm) for sm in samples]
+        raw = [sum(a.elapsed_time(b) for a, b in sm) / len(sm) for sm in samples]
+        return [max(0.0, r - raw[n]) for r in raw[:n]], raw[n]
 
     def emit(self, out):
         if self.rank == 0:
@@ -347,7 +354,7 @@ def headline(args):
     def p_dec():
         dec((state["k"] + 1) % NS)
         state["k"] += 1
-    gemm_ms, dec_ms = R_.sampled_ms([p_enc, p_dec], args.steps)
+    (gemm_ms, dec_ms), pair_ms = R_.sampled_ms([p_enc, p_dec], args.steps)
     achieved_tops = ops_per_enc * B / (gemm_ms * 1e-3) / 1e12
     dec_gbs = B * (n + 1) * 4 / (dec_ms * 1e-3) / 1e9
 
@@ -372,12 +379,12 @@ def headline(args):
         "config": {"workload": "Regev enc+dec round trip (BASELINE config 2)", "n": n, "m": m, "q": q,
                    "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"batch-shard x{world}",
                    "buffer_sets": NS, "key_broadcast_ms": t_bcast * 1e3},
-        "ms_per_step_events": region_ms / args.steps,
+        "ms_per_step_events": region_ms / args.steps, "event_pair_overhead_ms": pair_ms,
         "roofline": {"kernel": "qf_gemm_packed_kernel<3,3> (bit operands, packed remainder row block)", "bound": "mfma",
                      "achieved": achieved_tops, "peak": INT8_PEAK_TOPS, "unit": "TOP/s", "frac": achieved_tops / INT8_PEAK_TOPS,
                      "traffic": pmc_traffic("regev", "qf_gemm_") if B == 65536 else None, "launch_ms": gemm_ms,
                      "note": "int8 multiply-accumulates counted as 2 ops; algorithmic ops = 2*La*Lb*(n+1)*m per encryption x B per launch; "
-                             "launch_ms = mean of HIP-event pairs around sampled GEMM launches in a second, untimed pass of the same step loop; "
+                             "launch_ms = mean of HIP-event pairs around sampled GEMM launches in a second, untimed pass of the same step loop, minus the reading of an empty event pair (event_pair_overhead_ms); "
                              "traffic = HBM bytes per launch from the committed PMC passes (profiles/r2/regev/traffic.json)"},
         "decode": {"kernel": "qf_dot_decode_kernel", "bound": "hbm", "launch_ms": dec_ms, "achieved": dec_gbs, "peak": HBM_PEAK_GBS,
                    "unit": "GB/s", "frac": dec_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("regev", "qf_dot_decode") if B == 65536 else None,

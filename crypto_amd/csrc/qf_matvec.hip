@@ -307,6 +307,8 @@ __device__ __forceinline__ uint32_t wave_sum_modq(uint32_t v, uint32_t q) {
     a += b;
     return min(a, a - q);
 }
+// 16-byte loads that need only 4-byte alignment (ciphertext rows are 4(n+1) bytes apart: 1,028 at n = 256)
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 __global__ __launch_bounds__(256) void qf_dot_decode_kernel(const uint32_t *__restrict__ w, uint32_t n,
                                                             QfMod mod, const uint32_t *__restrict__ C,
                                                             uint64_t B, uint8_t *__restrict__ bits) {
@@ -314,6 +316,7 @@ __global__ __launch_bounds__(256) void qf_dot_decode_kernel(const uint32_t *__re
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint32_t stride = n + 1;
+    const uint32_t nvec = n & ~3u;       // columns covered by whole 4-word groups
     for (uint64_t b0 = wave * DEC_U; b0 < B; b0 += nwaves * DEC_U) {
         const uint32_t *c[DEC_U];
         Acc2 acc[DEC_U];
@@ -323,14 +326,31 @@ __global__ __launch_bounds__(256) void qf_dot_decode_kernel(const uint32_t *__re
             c[u] = C + b * stride;
             acc[u].lo = 0; acc[u].hi = 0;
         }
+        // a lane takes 4 adjacent columns per step (one 16-byte load per ciphertext: a whole 1-KiB run per
+        // wave instruction, DEC_U of them in flight), the same 4 entries of w serve all DEC_U ciphertexts
+        for (uint32_t i = 4 * lane; i < nvec; i += 256) {
+            const u32x4_a4 wv = *(const u32x4_a4 *)(w + i);
+            u32x4_a4 cv[DEC_U];
+#pragma unroll
+            for (int u = 0; u < DEC_U; u++) cv[u] = *(const u32x4_a4 *)(c[u] + i);
+#pragma unroll
+            for (int u = 0; u < DEC_U; u++) {
+                acc_mad(acc[u], wv.x, cv[u].x); acc_mad(acc[u], wv.y, cv[u].y);
+                acc_mad(acc[u], wv.z, cv[u].z); acc_mad(acc[u], wv.w, cv[u].w);
+            }
+        }
+        // the n mod 4 trailing columns and the ciphertext's last entry c[n] (coefficient 1): lanes 0..3
         uint32_t last[DEC_U];
 #pragma unroll
-        for (int u = 0; u < DEC_U; u++) last[u] = lane == 0 ? c[u][n] : 0u;
-#pragma unroll 4
-        for (uint32_t i = lane; i < n; i += 64) {
-            const uint32_t wv = w[i];
+        for (int u = 0; u < DEC_U; u++) last[u] = 0;
+        if ((uint32_t)lane <= n - nvec) {
+            const uint32_t i = nvec + lane;              // i == n: the last entry
+            const uint32_t wt = i < n ? w[i] : 0u;
 #pragma unroll
-            for (int u = 0; u < DEC_U; u++) acc_mad(acc[u], wv, c[u][i]);
+            for (int u = 0; u < DEC_U; u++) {
+                const uint32_t cvs = c[u][i];
+                if (i < n) acc_mad(acc[u], wt, cvs); else last[u] = cvs;
+            }
         }
 #pragma unroll
         for (int u = 0; u < DEC_U; u++) {

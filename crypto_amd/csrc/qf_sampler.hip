@@ -9,19 +9,23 @@ __global__ void qf_sample_uniform_kernel(uint64_t base, uint64_t first, uint64_t
     for (; i < count; i += stride) out[i] = qf_rand_below(base, first + i, q);
 }
 
-// one thread per output dword (32 bits); stride_bytes must be a multiple of 4
+// Bit rows: row r takes W64 = ceil(cols / 64) generator values; bit j of the row is bit (j & 63) of
+// value((first_row + r) * W64 + (j >> 6)) -- all 64 bits of a draw are used (one SplitMix64 per bit made
+// this kernel VALU-bound: 174 us for 65,536 x 6,168 bits, 60 % of the GEMM that consumes them; now it
+// writes at HBM speed).  One thread per output dword; stride_bytes is a multiple of 4.
 __global__ void qf_sample_bits_kernel(uint64_t base, uint64_t first_row, uint64_t rows, uint32_t cols,
                                       uint32_t stride_bytes, uint8_t *__restrict__ out) {
-    const uint32_t wpr = stride_bytes / 4;
+    const uint32_t wpr = stride_bytes / 4, w64 = (cols + 63) / 64;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t total = rows * wpr, stride = (uint64_t)gridDim.x * blockDim.x;
     for (; i < total; i += stride) {
         const uint64_t r = i / wpr;
-        const uint32_t j0 = (uint32_t)(i % wpr) * 32;
+        const uint32_t d = (uint32_t)(i % wpr), j0 = d * 32;      // this dword holds bits j0 .. j0+31 of the row
         uint32_t word = 0;
-        for (uint32_t t = 0; t < 32; t++) {
-            uint32_t j = j0 + t;
-            if (j < cols) word |= (uint32_t)(qf_rand64(base, (first_row + r) * cols + j) & 1) << t;
+        if (j0 < cols) {
+            const uint64_t v = qf_rand64(base, (first_row + r) * w64 + (d >> 1));
+            word = (uint32_t)(v >> (32 * (d & 1)));
+            if (cols - j0 < 32) word &= (1u << (cols - j0)) - 1u;   // padding bits are zero
         }
         ((uint32_t *)out)[i] = word;
     }

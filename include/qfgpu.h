@@ -202,7 +202,8 @@ int qf_hash_to_mat_zq_sha256_dev(qf_ctx *ctx, const uint8_t *msgs_dev, const uin
  * on inputs produced by this counter-mode SplitMix64 generator, implemented identically in
  * oracle/qf_oracle.c:  value = splitmix64((seed ^ (stream << 48)) + idx).
  *   uniform : (value * q) >> 64                       for idx = first .. first+count-1
- *   bits    : value & 1 at idx = (first_row+r)*cols + j, packed LSB-first, padding bits 0
+ *   bits    : row r takes W64 = ceil(cols/64) values; bit j = bit (j & 63) of value at idx
+ *             (first_row+r)*W64 + (j >> 6); packed LSB-first, padding bits 0
  *   noise   : sum of 4 uniform integers in [-W,W] (idx*4+t), stored mod q  (Gaussian stand-in) */
 int qf_sample_uniform_dev(qf_ctx *ctx, uint64_t seed, uint32_t stream, uint64_t first, uint64_t count,
                           uint32_t q, uint32_t *out_dev);

@@ -56,7 +56,9 @@ def sample_noise(seed, stream, first, count, q, W):
 
 
 def sample_bits(seed, stream, first_row, rows, cols):
-    return [[rand64(seed, stream, (first_row + r) * cols + j) & 1 for j in range(cols)]
+    """bit j of row r = bit (j & 63) of value((first_row + r) * ceil(cols/64) + (j >> 6))"""
+    w64 = (cols + 63) // 64
+    return [[(rand64(seed, stream, (first_row + r) * w64 + (j >> 6)) >> (j & 63)) & 1 for j in range(cols)]
             for r in range(rows)]
 
 

@@ -79,14 +79,15 @@ void qfo_sample_uniform(uint64_t seed, uint32_t stream, uint64_t first, uint64_t
                         uint32_t q, uint32_t *out) {
     for (uint64_t i = 0; i < count; i++) out[i] = rand_below(seed, stream, first + i, q);
 }
-/* bit-packed uniform bits: row r occupies stride_bytes bytes, bit j of row r comes from
- * counter (first_row + r)*cols + j ; padding bits are zero */
+/* bit-packed uniform bits: row r occupies stride_bytes bytes and takes W64 = ceil(cols/64) generator
+ * values; bit j of row r is bit (j & 63) of value((first_row + r)*W64 + (j >> 6)); padding bits are zero */
 void qfo_sample_bits(uint64_t seed, uint32_t stream, uint64_t first_row, uint64_t rows,
                      uint32_t cols, uint32_t stride_bytes, uint8_t *out) {
+    const uint64_t w64 = ((uint64_t)cols + 63) / 64;
     memset(out, 0, (size_t)rows * stride_bytes);
     for (uint64_t r = 0; r < rows; r++)
         for (uint32_t j = 0; j < cols; j++)
-            if (qfo_rand64(seed, stream, (first_row + r) * cols + j) & 1)
+            if ((qfo_rand64(seed, stream, (first_row + r) * w64 + (j >> 6)) >> (j & 63)) & 1)
                 out[r * stride_bytes + (j >> 3)] |= (uint8_t)(1u << (j & 7));
 }
 /* Gaussian stand-in: sum of 4 independent uniform integers in [-W,W], stored mod q */
