@@ -691,7 +691,7 @@ def other_workloads(args):
         from crypto_amd.construction.pk_encryption import Regev
         rows = []
         for nn in (10, 20, 30, 40, 50, 60):
-            r = Regev.new_from_n(nn, ctx=ctx)
+            r = Regev.new_from_n(nn, ctx=ctx, seed=SEED, noise_model="irwin_hall")   # the noise model the CPU port draws
             W = r.noise_width
             reps = 20
             t1 = time.perf_counter()

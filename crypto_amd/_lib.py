@@ -52,6 +52,7 @@ SYMBOLS = {
     "qf_vecmat_modq_host": (_i, [_vp, _vp, _vp, _vp]),
     "qf_matvec_modq_dev": (_i, [_vp, _vp, _vp, _vp]),
     "qf_vecmat_modq_dev": (_i, [_vp, _vp, _vp, _vp]),
+    "qf_vecmat_u32_dev": (_i, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "qf_matvec_modq_static_dev": (_i, [_vp, _vp, _vp, _vp]),
     "qf_dot_decode_dev": (_i, [_vp, _vp, _u32, _u32, _vp, _u64, _vp]),
     "qf_hash_to_mat_zq_sha256_dev": (_i, [_vp, _vp, _vp, _u64, _u32, _u32, _u32, _vp]),

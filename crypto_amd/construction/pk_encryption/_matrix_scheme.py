@@ -28,6 +28,26 @@ class MatrixSchemeMixin:
             mat._dev[tag] = key
         return key
 
+    def _lwe_keypair(self, n: int, m: int, secret_from_chi: bool):
+        """pk = [A ; s^t A + e^t], sk = s (regev.rs:350-374 with s uniform, lpr.rs:338-370 with s <- chi).
+        Everything is drawn and multiplied on the device, straight into one image [pk | s]; the host
+        gets one copy of it, and pk's digit planes are built from the device image (so the first enc
+        under this key uploads nothing)."""
+        q, ctx, rng, W = self.q, self.ctx, self.rng, self.noise_width
+        img = ctx.empty_u32((n + 1) * m + n)
+        pk_dev, s_dev = img[:(n + 1) * m].view(n + 1, m), img[(n + 1) * m:]
+        ctx.sample_uniform(rng.seed, 1, rng._take(1, n * m), n * m, q, out=pk_dev[:n])
+        if secret_from_chi:
+            s_dev.copy_(rng.noise_dev(2, n, q, W))
+        else:
+            ctx.sample_uniform(rng.seed, 2, rng._take(2, n), n, q, out=s_dev)
+        e_dev = rng.noise_dev(4, m, q, W)
+        ctx.vecmat_u32(pk_dev[:n], q, s_dev, addend=e_dev, out=pk_dev[n])
+        host = ctx.to_host_u32(img)
+        pk = MatZq.from_canonical(host[:(n + 1) * m].reshape(n + 1, m), q)
+        pk._dev[(id(ctx), False)] = ctx.key_upload(pk_dev, q)
+        return pk, MatZq.from_canonical(host[(n + 1) * m:].reshape(n, 1), q)
+
     def _check_pk(self, pk: MatZq, rows: int, cols: int):
         # the reference panics on mismatching dimensions / moduli inside qfall-math
         if not isinstance(pk, MatZq):
@@ -39,8 +59,14 @@ class MatrixSchemeMixin:
 
     def _decode_batch(self, w: np.ndarray, ciphers) -> np.ndarray:
         """bits = decision rule applied to <w, c[:-1]> + c[-1] for each row of `ciphers`."""
-        c = ciphers if not isinstance(ciphers, np.ndarray) else self.ctx.to_dev_u32(ciphers)
-        bits = self.ctx.dot_decode(self.ctx.to_dev_u32(w), self.q, c)
+        if isinstance(ciphers, np.ndarray):
+            # weights and ciphertexts cross PCIe as ONE buffer (a single-ciphertext call is all latency)
+            c2 = np.ascontiguousarray(ciphers, dtype=np.uint32)
+            both = self.ctx.to_dev_u32(np.concatenate([np.asarray(w, np.uint32).reshape(-1), c2.reshape(-1)]))
+            wd, c = both[:w.size], both[w.size:].view(c2.shape)
+        else:
+            wd, c = self.ctx.to_dev_u32(w), ciphers
+        bits = self.ctx.dot_decode(wd, self.q, c)
         return self.ctx.to_host_u8(bits)
 
 

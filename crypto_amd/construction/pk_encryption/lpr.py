@@ -88,14 +88,7 @@ class LPR(MatrixSchemeMixin, GenericMultiBitEncryption):
 
     def gen(self):
         """lpr.rs:338-370: A <- Z_q^{n x n}, s,e <- chi^n, b^t = s^t A + e^t, pk = [A ; b^t]."""
-        n, q, W = self.n, self.q, self.noise_width
-        A = self.rng.uniform(1, n * n, q).reshape(n, n)
-        s = self.rng.noise(2, n, q, W)
-        e = self.rng.noise(4, n, q, W)
-        key_a = self.ctx.key_upload(A, q)
-        b = (self.ctx.vecmat(key_a, s).astype(np.uint64) + e) % q
-        key_a.close()
-        return MatZq(np.vstack([A, b.astype(np.uint32)[None, :]]), q), MatZq(s[:, None], q)
+        return self._lwe_keypair(self.n, self.n, secret_from_chi=True)
 
     def enc(self, pk: MatZq, message, r=None, e=None) -> MatZq:
         """lpr.rs:394-430: c = pk*r + e + [0..0, msg*floor(q/2)]^t."""

@@ -88,15 +88,7 @@ class Regev(MatrixSchemeMixin, GenericMultiBitEncryption):
 
     def gen(self):
         """regev.rs:350-374: A <- Z_q^{n x m}, s <- Z_q^n, e <- chi^m, b^t = s^t A + e^t, pk = [A ; b^t]."""
-        n, m, q = self.n, self.m, self.q
-        A = self.rng.uniform(1, n * m, q).reshape(n, m)
-        s = self.rng.uniform(2, n, q)
-        e = self.rng.noise(4, m, q, self.noise_width)
-        key_a = self.ctx.key_upload(A, q)
-        b = (self.ctx.vecmat(key_a, s).astype(np.uint64) + e) % q
-        key_a.close()
-        pk = MatZq(np.vstack([A, b.astype(np.uint32)[None, :]]), q)
-        return pk, MatZq(s[:, None], q)
+        return self._lwe_keypair(self.n, self.m, secret_from_chi=False)
 
     def enc(self, pk: MatZq, message, x=None) -> MatZq:
         """regev.rs:396-414: c = pk*x + [0..0, (message mod 2)*floor(q/2)]^t, x <- {0,1}^m."""
@@ -106,7 +98,7 @@ class Regev(MatrixSchemeMixin, GenericMultiBitEncryption):
             x = self.rng.bits(3, self.m)
         c = self.ctx.matvec(self._dev_key(pk), np.asarray(x, np.uint32))
         c[-1] = (int(c[-1]) + msg * (self.q // 2)) % self.q
-        return MatZq(c[:, None], self.q)
+        return MatZq.from_canonical(c.reshape(-1, 1), self.q)
 
     def dec(self, sk: MatZq, cipher: MatZq) -> int:
         """regev.rs:438-452."""

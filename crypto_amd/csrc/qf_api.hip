@@ -4,6 +4,8 @@
 #include <cstring>
 #include <new>
 #include <vector>
+#include <mutex>
+#include <vector>
 #include "qf_internal.h"
 #include "qf_ring.h"
 
@@ -156,27 +158,69 @@ int qf_memcpy_d2h(qf_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes
 }
 
 // ------------------------------------------------------------------ keys
-static int key_build(qf_ctx *ctx, uint32_t *u32_dev_owned, uint32_t rows, uint32_t cols, uint32_t q, qf_key **out) {
+// One device allocation per key: [uint32 copy | digit planes | packed remainder planes], each part
+// 256-byte aligned (three hipMalloc/hipFree pairs per key were most of a small key's upload time).
+// key_alloc sizes and carves the block; the caller fills k->u32 on ctx->stream; key_finish recodes.
+static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+// Freed key blocks of up to 16 MiB are parked (at most 8 per process) and handed to the next key of
+// exactly the same size on the same device: a host that regenerates small keys in a loop (the
+// reference's own bench does, benches/regev.rs:15-57) pays no hipMalloc/hipFree per key.
+struct ParkedBlock { int device; size_t bytes; void *ptr; };
+static std::mutex g_park_mu;
+static std::vector<ParkedBlock> g_parked;
+static const size_t PARK_MAX_BYTES = 16u << 20, PARK_MAX_BLOCKS = 8;
+static void *park_take(int device, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_park_mu);
+    for (size_t i = 0; i < g_parked.size(); i++)
+        if (g_parked[i].device == device && g_parked[i].bytes == bytes) {
+            void *p = g_parked[i].ptr;
+            g_parked.erase(g_parked.begin() + i);
+            return p;
+        }
+    return nullptr;
+}
+// true if the block was kept (the caller must have synchronised the device first)
+static bool park_give(int device, size_t bytes, void *ptr) {
+    if (bytes > PARK_MAX_BYTES) return false;
+    void *evict = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_park_mu);
+        if (g_parked.size() >= PARK_MAX_BLOCKS) { evict = g_parked.front().ptr; hipSetDevice(g_parked.front().device); g_parked.erase(g_parked.begin()); }
+        g_parked.push_back({device, bytes, ptr});
+    }
+    if (evict) { hipFree(evict); hipSetDevice(device); }
+    return true;
+}
+static int key_alloc(qf_ctx *ctx, uint32_t rows, uint32_t cols, uint32_t q, qf_key **out) {
     qf_key *k = new (std::nothrow) qf_key();
-    if (!k) { hipFree(u32_dev_owned); return qf_fail(ctx, QF_ERR_DEVICE, "out of host memory"); }
+    if (!k) return qf_fail(ctx, QF_ERR_DEVICE, "out of host memory");
     k->device = ctx->device; k->rows = rows; k->cols = cols; k->q = q;
     k->mod = qf_make_mod(q);
     k->la = qf_digits_for_modulus(q);
     k->rb = (rows + 31) / 32;
     k->ks = ((cols + 127) / 128) * 4;
-    k->u32 = u32_dev_owned;
-    size_t pbytes = (size_t)k->rb * k->ks * k->la * 1024;
-    hipError_t e = hipMalloc((void **)&k->planes, pbytes);
-    if (e != hipSuccess) { hipFree(k->u32); delete k; ctx->err = "hipMalloc(key planes) failed"; return QF_ERR_DEVICE; }
-    int rc = qf_launch_recode(ctx, k->u32, QF_X_U32, (size_t)cols * 4, rows, cols, k->mod, k->la, k->ks, k->planes, ctx->flag);
-    if (rc) { qf_key_destroy(k); return rc; }
     const uint32_t r = rows % 32;
-    if (r && r * (uint32_t)k->la <= 32) {
-        if (hipMalloc((void **)&k->rem_planes, (size_t)k->ks * 1024) != hipSuccess) { qf_key_destroy(k); return qf_fail(ctx, QF_ERR_DEVICE, "hipMalloc(key remainder planes) failed"); }
-        k->rem_rows = r;
-        rc = qf_launch_recode_rem(ctx, k->u32, cols, rows - r, r, k->mod, k->la, k->ks, k->rem_planes);
-        if (rc) { qf_key_destroy(k); return rc; }
+    if (r && r * (uint32_t)k->la <= 32) k->rem_rows = r;
+    const size_t ubytes = align256((size_t)rows * cols * 4);
+    const size_t pbytes = align256((size_t)k->rb * k->ks * k->la * 1024);
+    const size_t rbytes = k->rem_rows ? (size_t)k->ks * 1024 : 0;
+    k->block_bytes = ubytes + pbytes + rbytes;
+    k->block = park_take(ctx->device, k->block_bytes);
+    if (!k->block && hipMalloc((void **)&k->block, k->block_bytes) != hipSuccess) {
+        delete k;
+        return qf_fail(ctx, QF_ERR_DEVICE, "hipMalloc(key) failed");
     }
+    k->u32 = (uint32_t *)k->block;
+    k->planes = (int8_t *)k->block + ubytes;
+    k->rem_planes = k->rem_rows ? (int8_t *)k->block + ubytes + pbytes : nullptr;
+    *out = k;
+    return QF_OK;
+}
+static int key_finish(qf_ctx *ctx, qf_key *k, qf_key **out) {
+    int rc = qf_launch_recode(ctx, k->u32, QF_X_U32, (size_t)k->cols * 4, k->rows, k->cols, k->mod, k->la, k->ks, k->planes, ctx->flag);
+    if (!rc && k->rem_rows)
+        rc = qf_launch_recode_rem(ctx, k->u32, k->cols, k->rows - k->rem_rows, k->rem_rows, k->mod, k->la, k->ks, k->rem_planes);
+    if (rc) { qf_key_destroy(k); return rc; }
     uint32_t flag = 0;
     if (hipMemcpyAsync(&flag, ctx->flag, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess) { qf_key_destroy(k); return qf_fail(ctx, QF_ERR_DEVICE, "key recode failed"); }
@@ -193,16 +237,17 @@ int qf_key_upload_dev(qf_ctx *ctx, const uint32_t *A_dev, uint32_t rows, uint32_
     int rc = check_q(ctx, q);
     if (rc) return rc;
     QF_BIND(ctx);
-    uint32_t *copy = nullptr;
-    QF_HIP(ctx, hipMalloc((void **)&copy, (size_t)rows * cols * 4));
+    qf_key *k = nullptr;
+    rc = transpose ? key_alloc(ctx, cols, rows, q, &k) : key_alloc(ctx, rows, cols, q, &k);
+    if (rc) return rc;
     if (transpose) {
-        rc = qf_launch_transpose_u32(ctx, A_dev, rows, cols, copy);
-        if (rc) { hipFree(copy); return rc; }
-        return key_build(ctx, copy, cols, rows, q, out);
+        rc = qf_launch_transpose_u32(ctx, A_dev, rows, cols, k->u32);
+        if (rc) { qf_key_destroy(k); return rc; }
+    } else if (hipMemcpyAsync(k->u32, A_dev, (size_t)rows * cols * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+        qf_key_destroy(k);
+        return qf_fail(ctx, QF_ERR_DEVICE, "key copy failed");
     }
-    hipError_t e = hipMemcpyAsync(copy, A_dev, (size_t)rows * cols * 4, hipMemcpyDeviceToDevice, ctx->stream);
-    if (e != hipSuccess) { hipFree(copy); ctx->err = "key copy failed"; return QF_ERR_DEVICE; }
-    return key_build(ctx, copy, rows, cols, q, out);
+    return key_finish(ctx, k, out);
 }
 int qf_key_upload_host(qf_ctx *ctx, const uint32_t *A_host, uint32_t rows, uint32_t cols, uint32_t q,
                        int transpose, qf_key **out) {
@@ -212,8 +257,18 @@ int qf_key_upload_host(qf_ctx *ctx, const uint32_t *A_host, uint32_t rows, uint3
     int rc = check_q(ctx, q);
     if (rc) return rc;
     QF_BIND(ctx);
+    const size_t bytes = (size_t)rows * cols * 4;
+    if (!transpose) {   // H2D straight into the key's own copy
+        qf_key *k = nullptr;
+        rc = key_alloc(ctx, rows, cols, q, &k);
+        if (rc) return rc;
+        if (hipMemcpyAsync(k->u32, A_host, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+            qf_key_destroy(k);
+            return qf_fail(ctx, QF_ERR_DEVICE, "key H2D copy failed");
+        }
+        return key_finish(ctx, k, out);   // synchronises: the host buffer is the caller's again on return
+    }
     uint32_t *tmp = nullptr;
-    size_t bytes = (size_t)rows * cols * 4;
     QF_HIP(ctx, hipMalloc((void **)&tmp, bytes));
     hipError_t e = hipMemcpyAsync(tmp, A_host, bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -226,11 +281,9 @@ int qf_key_upload_host(qf_ctx *ctx, const uint32_t *A_host, uint32_t rows, uint3
 void qf_key_destroy(qf_key *key) {
     if (!key) return;
     hipSetDevice(key->device);
-    hipDeviceSynchronize();
-    if (key->planes) hipFree(key->planes);
-    if (key->rem_planes) hipFree(key->rem_planes);
+    hipDeviceSynchronize();   // launches that read the key may still be in flight on any stream
     for (int8_t *f : key->fold_planes) if (f) hipFree(f);
-    if (key->u32) hipFree(key->u32);
+    if (key->block && !park_give(key->device, key->block_bytes, key->block)) hipFree(key->block);
     delete key;
 }
 int qf_key_dims(const qf_key *key, uint32_t *rows, uint32_t *cols, uint32_t *q) {
@@ -252,15 +305,15 @@ int qf_key_replicate(qf_ctx *const *ctxs, int n, const qf_key *src, qf_key **out
     for (int i = 0; i < n; i++) {
         qf_ctx *ctx = ctxs[i];
         int rc = QF_OK;
-        uint32_t *copy = nullptr;
-        if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc((void **)&copy, bytes) != hipSuccess) {
-            rc = qf_fail(ctx, QF_ERR_DEVICE, "key replicate: allocation on the target device failed");
-        } else {
+        qf_key *k = nullptr;
+        if (hipSetDevice(ctx->device) != hipSuccess) rc = qf_fail(ctx, QF_ERR_DEVICE, "key replicate: cannot select the target device");
+        else rc = key_alloc(ctx, src->rows, src->cols, src->q, &k);
+        if (!rc) {
             hipError_t e = ctx->device == src->device
-                               ? hipMemcpyAsync(copy, src->u32, bytes, hipMemcpyDeviceToDevice, ctx->stream)
-                               : hipMemcpyPeerAsync(copy, ctx->device, src->u32, src->device, bytes, ctx->stream);
-            if (e != hipSuccess) { hipFree(copy); rc = qf_fail(ctx, QF_ERR_DEVICE, "key replicate: device-to-device copy failed"); }
-            else rc = key_build(ctx, copy, src->rows, src->cols, src->q, &out[i]);   // takes ownership of `copy`
+                               ? hipMemcpyAsync(k->u32, src->u32, bytes, hipMemcpyDeviceToDevice, ctx->stream)
+                               : hipMemcpyPeerAsync(k->u32, ctx->device, src->u32, src->device, bytes, ctx->stream);
+            if (e != hipSuccess) { qf_key_destroy(k); rc = qf_fail(ctx, QF_ERR_DEVICE, "key replicate: device-to-device copy failed"); }
+            else rc = key_finish(ctx, k, &out[i]);
         }
         if (rc) {
             for (int j = 0; j < i; j++) { qf_key_destroy(out[j]); out[j] = nullptr; }
@@ -327,6 +380,15 @@ int qf_vecmat_modq_dev(qf_ctx *ctx, const qf_key *key, const uint32_t *x_dev, ui
     if (!ctx || !key || !x_dev || !y_dev) return QF_ERR_ARG;
     QF_BIND(ctx);
     return qf_launch_vecmat(ctx, key, x_dev, y_dev);
+}
+int qf_vecmat_u32_dev(qf_ctx *ctx, const uint32_t *A_dev, uint32_t rows, uint32_t cols, uint32_t q,
+                      const uint32_t *x_dev, const uint32_t *addend_dev, uint32_t *y_dev) {
+    if (!ctx || !A_dev || !x_dev || !y_dev) return QF_ERR_ARG;
+    if (!rows || !cols) return qf_fail(ctx, QF_ERR_DIM, "vecmat: matrix with zero rows or columns");
+    int rc = check_q(ctx, q);
+    if (rc) return rc;
+    QF_BIND(ctx);
+    return qf_launch_vecmat_raw(ctx, A_dev, rows, cols, qf_make_mod(q), x_dev, addend_dev, y_dev);
 }
 int qf_matvec_modq_static_dev(qf_ctx *ctx, const qf_key *key, const uint32_t *x_dev, uint32_t *y_dev) {
     if (!ctx || !key || !x_dev || !y_dev) return QF_ERR_ARG;

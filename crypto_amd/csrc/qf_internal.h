@@ -36,6 +36,8 @@ struct qf_key {
     int la = 0;         // signed 8-bit digits per entry
     uint32_t rb = 0;    // row blocks of 32
     uint32_t ks = 0;    // k-steps of 32 (padded to a multiple of 4)
+    void *block = nullptr;     // the key's one device allocation: u32 | planes | rem_planes
+    size_t block_bytes = 0;
     int8_t *planes = nullptr;  // [rb][ks][la][64 lanes][16 B]   (MFMA fragment order)
     uint32_t *u32 = nullptr;   // rows x cols row-major copy
     // packed remainder block (bit-operand products): when r = rows mod 32 satisfies 0 < r*la <= 32
@@ -102,6 +104,8 @@ int qf_launch_transpose_u32(qf_ctx *ctx, const uint32_t *src, uint32_t rows, uin
 // qf_matvec.hip
 int qf_launch_matvec(qf_ctx *ctx, const qf_key *key, const uint32_t *x, uint32_t *y);
 int qf_launch_vecmat(qf_ctx *ctx, const qf_key *key, const uint32_t *x, uint32_t *y);
+int qf_launch_vecmat_raw(qf_ctx *ctx, const uint32_t *A, uint32_t rows, uint32_t cols, const QfMod &mod,
+                         const uint32_t *x, const uint32_t *addend, uint32_t *y);
 int qf_launch_matvec_static(qf_ctx *ctx, const qf_key *key, const uint32_t *x, uint32_t *y);
 int qf_static_scratch_init(qf_ctx *ctx);   // resolves the per-device address of the static scratch array
 int qf_launch_dot_decode(qf_ctx *ctx, const uint32_t *w, uint32_t n, const QfMod &mod, const uint32_t *C,

@@ -260,28 +260,34 @@ __global__ __launch_bounds__(MV_BLOCK) void qf_vecmat_partial(const uint32_t *__
     }
 }
 __global__ void qf_vecmat_finish(const Acc2 *__restrict__ partial, uint32_t cols, uint32_t nchunk,
-                                 QfMod mod, uint32_t *__restrict__ y) {
+                                 QfMod mod, const uint32_t *__restrict__ addend, uint32_t *__restrict__ y) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= cols) return;
     uint64_t lo = 0, hi = 0;
     for (uint32_t c = 0; c < nchunk; c++) { lo += partial[(size_t)c * cols + j].lo; hi += partial[(size_t)c * cols + j].hi; }
-    y[j] = acc_finish(lo, hi, mod);
+    uint32_t v = acc_finish(lo, hi, mod);
+    if (addend) v = qf_red_u64((uint64_t)v + addend[j], mod);
+    y[j] = v;
 }
 
-int qf_launch_vecmat(qf_ctx *ctx, const qf_key *key, const uint32_t *x, uint32_t *y) {
-    uint32_t nchunk = (key->rows + VM_ROWS - 1) / VM_ROWS;
-    int rc = qf_ws2_reserve(ctx, (size_t)key->cols * nchunk * sizeof(Acc2));
+// y^t = x^t*A (+ addend^t) for a plain row-major uint32 matrix on the device (no key object)
+int qf_launch_vecmat_raw(qf_ctx *ctx, const uint32_t *A, uint32_t rows, uint32_t cols, const QfMod &mod,
+                         const uint32_t *x, const uint32_t *addend, uint32_t *y) {
+    uint32_t nchunk = (rows + VM_ROWS - 1) / VM_ROWS;
+    int rc = qf_ws2_reserve(ctx, (size_t)cols * nchunk * sizeof(Acc2));
     if (rc) return rc;
-    dim3 grid((key->cols + MV_BLOCK * 4 - 1) / (MV_BLOCK * 4), nchunk), block(MV_BLOCK);
+    dim3 grid((cols + MV_BLOCK * 4 - 1) / (MV_BLOCK * 4), nchunk), block(MV_BLOCK);
     {
         QfTimer t(ctx, &ctx->ms_matvec);
-        hipLaunchKernelGGL(qf_vecmat_partial, grid, block, 0, ctx->stream, key->u32, key->rows, key->cols, x,
-                           (Acc2 *)ctx->ws2);
+        hipLaunchKernelGGL(qf_vecmat_partial, grid, block, 0, ctx->stream, A, rows, cols, x, (Acc2 *)ctx->ws2);
     }
-    hipLaunchKernelGGL(qf_vecmat_finish, dim3((key->cols + 255) / 256), dim3(256), 0, ctx->stream,
-                       (const Acc2 *)ctx->ws2, key->cols, nchunk, key->mod, y);
+    hipLaunchKernelGGL(qf_vecmat_finish, dim3((cols + 255) / 256), dim3(256), 0, ctx->stream,
+                       (const Acc2 *)ctx->ws2, cols, nchunk, mod, addend, y);
     QF_HIP(ctx, hipGetLastError());
     return QF_OK;
+}
+int qf_launch_vecmat(qf_ctx *ctx, const qf_key *key, const uint32_t *x, uint32_t *y) {
+    return qf_launch_vecmat_raw(ctx, key->u32, key->rows, key->cols, key->mod, x, nullptr, y);
 }
 
 // Batched decryption: a wave handles DEC_U ciphertexts per iteration (all their loads in flight

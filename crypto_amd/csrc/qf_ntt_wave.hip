@@ -130,8 +130,12 @@ struct Wv {
                     const uint32_t ti = m + (L::cpart(r) >> (b + 1));
                     w = tw_g[ti]; wp = tw_g[N + ti];
                 } else {
+#ifdef QF_ABL_NOTWLDS
+                    w = tw_g[m]; wp = tw_g[N + m];
+#else
                     const uint2 t2 = tw_lds[m + ((lp | L::cpart(r)) >> (b + 1))];
                     w = t2.x; wp = t2.y;
+#endif
                 }
                 if (FWD) bf_fwd<LAZY>(x[r], x[hi], w, wp, q, q2);
                 else bf_inv<LAZY>(x[r], x[hi], w, wp, q, q2);
@@ -141,6 +145,9 @@ struct Wv {
 
     template <int PF, int PT>
     static __device__ __forceinline__ void transpose(uint32_t (&x)[R], uint32_t lane, uint32_t *buf) {
+#ifdef QF_ABL_NOTRANSPOSE
+        return;
+#endif
         const uint32_t wa = qf_swz<LG>(Ph<LG, PF>::lpart(lane)), ra = qf_swz<LG>(Ph<LG, PT>::lpart(lane));
 #pragma unroll
         for (int r = 0; r < R; r++) buf[wa ^ qf_swz<LG>(Ph<LG, PF>::cpart(r))] = x[r];

@@ -73,6 +73,17 @@ class MatZq:
         self.entries = np.ascontiguousarray(arr)
         self._dev = {}
 
+    @classmethod
+    def from_canonical(cls, entries: np.ndarray, q: int) -> "MatZq":
+        """Adopts a 2-D uint32 array whose entries are already canonical residues (what the device
+        library returns): no pass over the data."""
+        self = cls.__new__(cls)
+        assert entries.dtype == np.uint32 and entries.ndim == 2
+        self.q = int(q)
+        self.entries = np.ascontiguousarray(entries)
+        self._dev = {}
+        return self
+
     # -- qfall-math style accessors
     def get_num_rows(self): return self.entries.shape[0]
     def get_num_columns(self): return self.entries.shape[1]

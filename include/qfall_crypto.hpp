@@ -205,6 +205,16 @@ class Randomness {
             dev_->check(qf_sample_noise_dev(dev_->ctx(), seed_, stream, take(stream, count), count, q, W, b.get()));
         return b.download();
     }
+    // the same draws left in device memory (key generation keeps A, s and e there)
+    void uniform_dev(uint32_t stream, uint64_t count, uint32_t q, uint32_t *out_dev) {
+        dev_->check(qf_sample_uniform_dev(dev_->ctx(), seed_, stream, take(stream, count), count, q, out_dev));
+    }
+    void noise_dev(uint32_t stream, uint64_t count, uint32_t q, uint32_t W, uint32_t *out_dev) {
+        if (gauss_n_)
+            dev_->check(qf_sample_discrete_gauss_dev(dev_->ctx(), seed_, stream, take(stream, count), count, q, gauss_n_, gauss_s_, out_dev));
+        else
+            dev_->check(qf_sample_noise_dev(dev_->ctx(), seed_, stream, take(stream, count), count, q, W, out_dev));
+    }
     std::vector<uint32_t> bits(uint32_t stream, uint32_t count) {  // MatZ::sample_uniform(m,1,0,2)
         const uint32_t stride = ((count + 127) / 128) * 16;
         DevBuf<uint8_t> b(*dev_, stride);
@@ -284,6 +294,24 @@ inline std::vector<uint8_t> decode_batch(const Device &d, const std::vector<uint
     return bits.download();
 }
 
+// pk = [A ; s^t A + e^t], sk = s (regev.rs:350-374 with s uniform; lpr.rs:338-370 with s <- chi): A, s and e
+// are drawn into ONE device image [pk | s], the product runs on it (qf_vecmat_u32_dev), one copy comes back
+inline std::pair<MatZq, MatZq> lwe_keypair(const Device &d, Randomness &rng, uint32_t n, uint32_t m, uint32_t q,
+                                           bool secret_from_chi, uint32_t W) {
+    const size_t pkw = (size_t)(n + 1) * m;
+    DevBuf<uint32_t> img(d, pkw + n), e(d, m);
+    uint32_t *A = img.get(), *s = img.get() + pkw;
+    rng.uniform_dev(1, (uint64_t)n * m, q, A);
+    if (secret_from_chi) rng.noise_dev(2, n, q, W, s); else rng.uniform_dev(2, n, q, s);
+    rng.noise_dev(4, m, q, W, e.get());
+    d.check(qf_vecmat_u32_dev(d.ctx(), A, n, m, q, s, e.get(), A + (size_t)n * m));
+    const std::vector<uint32_t> h = img.download();
+    MatZq pk(n + 1, m, q), sk(n, 1, q);
+    std::copy(h.begin(), h.begin() + pkw, pk.e.begin());
+    std::copy(h.begin() + pkw, h.end(), sk.e.begin());
+    return {pk, sk};
+}
+
 // ---------------------------------------------------------------------------------------------
 // Regev (regev.rs)
 // ---------------------------------------------------------------------------------------------
@@ -321,18 +349,7 @@ class Regev : public PKEncryptionScheme<Regev, MatZq, MatZq, MatZq> {
     uint32_t noise_width() const { return gaussian_width(alpha * q); }
 
     // regev.rs:350-374: A <- Z_q^{n x m}, s <- Z_q^n, e <- chi^m, b^t = s^t A + e^t, pk = [A ; b^t]
-    std::pair<MatZq, MatZq> gen() {
-        MatZq A(n, m, q);
-        A.e = rng.uniform(1, (uint64_t)n * m, q);
-        MatZq sk(n, 1, q);
-        sk.e = rng.uniform(2, n, q);
-        std::vector<uint32_t> e = rng.noise(4, m, q, noise_width()), b(m);
-        { DevKey ka(*dev, A); dev->check(qf_vecmat_modq_host(dev->ctx(), ka.get(), sk.e.data(), b.data())); }
-        MatZq pk(n + 1, m, q);
-        std::copy(A.e.begin(), A.e.end(), pk.e.begin());
-        for (uint32_t j = 0; j < m; j++) pk.e[(size_t)n * m + j] = (uint32_t)(((uint64_t)b[j] + e[j]) % q);
-        return {pk, sk};
-    }
+    std::pair<MatZq, MatZq> gen() { return lwe_keypair(*dev, rng, n, m, q, false, noise_width()); }
     // regev.rs:396-414: c = pk*x + [0..0, (message mod 2)*floor(q/2)]^t, x <- {0,1}^m
     MatZq enc(const MatZq &pk, int64_t message, const std::vector<uint32_t> *x_in = nullptr) {
         check_pk(pk);
@@ -483,19 +500,7 @@ class LPR : public PKEncryptionScheme<LPR, MatZq, MatZq, MatZq> {
         while (cap < bound) { cap = cap * 256 + 127; d++; }
         return d;
     }
-    std::pair<MatZq, MatZq> gen() {  // lpr.rs:338-370
-        const uint32_t W = noise_width();
-        MatZq A(n, n, q);
-        A.e = rng.uniform(1, (uint64_t)n * n, q);
-        MatZq sk(n, 1, q);
-        sk.e = rng.noise(2, n, q, W);
-        std::vector<uint32_t> e = rng.noise(4, n, q, W), b(n);
-        { DevKey ka(*dev, A); dev->check(qf_vecmat_modq_host(dev->ctx(), ka.get(), sk.e.data(), b.data())); }
-        MatZq pk(n + 1, n, q);
-        std::copy(A.e.begin(), A.e.end(), pk.e.begin());
-        for (uint32_t j = 0; j < n; j++) pk.e[(size_t)n * n + j] = (uint32_t)(((uint64_t)b[j] + e[j]) % q);
-        return {pk, sk};
-    }
+    std::pair<MatZq, MatZq> gen() { return lwe_keypair(*dev, rng, n, n, q, true, noise_width()); }  // lpr.rs:338-370
     // lpr.rs:394-430: c = pk*r + e + [0..0, msg*floor(q/2)]^t
     MatZq enc(const MatZq &pk, int64_t message, const std::vector<uint32_t> *r_in = nullptr, const std::vector<uint32_t> *e_in = nullptr) {
         check_pk(pk);

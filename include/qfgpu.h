@@ -123,6 +123,12 @@ int qf_vecmat_modq_host(qf_ctx *ctx, const qf_key *key, const uint32_t *x_host, 
 /* device-pointer forms (asynchronous) used by the benchmarks */
 int qf_matvec_modq_dev(qf_ctx *ctx, const qf_key *key, const uint32_t *x_dev, uint32_t *y_dev);
 int qf_vecmat_modq_dev(qf_ctx *ctx, const qf_key *key, const uint32_t *x_dev, uint32_t *y_dev);
+/* y^t = x^t*A + addend^t (mod q) for a plain row-major rows x cols uint32 matrix in device memory --
+ * no key object, no digit planes: the one-off products of key generation, where A is used once as
+ * it comes out of the sampler: b^t = s^t*A + e^t (regev.rs:366-368), the rows of lpr.rs:362-364.
+ * A, x and addend may hold any uint32 values (reduced exactly); addend_dev may be NULL. */
+int qf_vecmat_u32_dev(qf_ctx *ctx, const uint32_t *A_dev, uint32_t rows, uint32_t cols, uint32_t q,
+                      const uint32_t *x_dev, const uint32_t *addend_dev, uint32_t *y_dev);
 /* qf_matvec_modq_dev for callers that cannot allocate device memory (code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same
  * result as qf_matvec_modq_dev; the cross-workgroup sums live in a file-scope device array of the

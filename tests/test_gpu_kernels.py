@@ -32,6 +32,23 @@ def test_matvec_vecmat(ctx, rows, cols, q):
     assert np.array_equal(ctx.vecmat(key, s), co.vecmat(s, A, q))
 
 
+@pytest.mark.parametrize("rows,cols,q", [(50, 867, 124991), (1, 3, 7), (130, 4099, 2147483629), (65, 1024, 8380417)])
+def test_vecmat_u32_with_addend(ctx, rows, cols, q):
+    """qf_vecmat_u32_dev: x^t*A + e^t on a plain device matrix (key generation, regev.rs:366-368), with
+    operands that are arbitrary uint32 values, into a row of a larger device matrix."""
+    A = co.sample_uniform(SEED, 1, 0, rows * cols, 2 ** 32 - 1).reshape(rows, cols)
+    s = co.sample_uniform(SEED, 2, 0, rows, 2 ** 32 - 1)
+    e = co.sample_uniform(SEED, 4, 0, cols, 2 ** 32 - 1)
+    red = lambda v: (v.astype(np.uint64) % q).astype(np.uint32)
+    want0 = co.vecmat(red(s), red(A), q)
+    want = ((want0.astype(np.uint64) + red(e)) % q).astype(np.uint32)
+    img = ctx.empty_u32(rows + 1, cols)
+    img[:rows].copy_(ctx.to_dev_u32(A))
+    ctx.vecmat_u32(img[:rows], q, ctx.to_dev_u32(s), addend=ctx.to_dev_u32(e), out=img[rows])
+    assert np.array_equal(ctx.to_host_u32(img[rows]), want)
+    assert np.array_equal(ctx.to_host_u32(ctx.vecmat_u32(img[:rows], q, ctx.to_dev_u32(s))), want0)
+
+
 @pytest.mark.parametrize("U", [1, 2, 3, 4])
 @pytest.mark.parametrize("rows,cols,q", [(512, 11776, 8380417), (257, 6168, 16777213), (70, 1300, 2147483629), (33, 50, 251)])
 def test_matvec_every_chunking(ctx, monkeypatch, rows, cols, q, U):

@@ -60,6 +60,26 @@ def test_regev_single_and_batch_agree_with_oracle(ctx):
     assert r.dec_batch(sk, cb).tolist() == co.dot_decode_batch(sk.entries[:, 0], r.q, cb).tolist()
 
 
+def test_regev_gen_on_device_matches_oracle(ctx):
+    """regev.rs:350-374 with the seeded generator: gen draws A, s, e and forms b^t = s^t A + e^t on the
+    device; the oracle redoes it from the same seed.  The key planes cached by gen serve the first enc."""
+    seed = 0xC0FFEE
+    r = Regev.new_from_n(30, ctx=ctx, seed=seed, noise_model="irwin_hall")
+    pk, sk = r.gen()
+    n, m, q = r.n, r.m, r.q
+    A = co.sample_uniform(seed, 1, 0, n * m, q).reshape(n, m)
+    s_ = co.sample_uniform(seed, 2, 0, n, q)
+    e = co.sample_noise(seed, 4, 0, m, q, r.noise_width)
+    b = ((co.vecmat(s_, A, q).astype(np.uint64) + e) % q).astype(np.uint32)
+    assert np.array_equal(pk.entries, np.vstack([A, b[None, :]]))
+    assert np.array_equal(sk.entries[:, 0], s_)
+    assert (id(ctx), False) in pk._dev
+    x = r.rng.bits(3, m)
+    assert r.enc(pk, 1, x=x).entries[:, 0].tolist() == po.regev_enc(pk.entries.tolist(), x.tolist(), 1, q)
+    pk2, sk2 = r.gen()                      # the streams advance: a second key pair is a different one
+    assert not np.array_equal(pk2.entries, pk.entries) and r.dec(sk2, r.enc(pk2, 1)) == 1
+
+
 def test_lpr_batch_round_trip_and_oracle(ctx):
     l = LPR.new_from_n(64, ctx=ctx)
     pk, sk = l.gen()
