@@ -228,6 +228,16 @@ struct QfSched {
     }
 };
 
+// Group of k-steps 2..3 (groups 2*NBF .. 4*NBF-1 of a tile) behind which LDS-DMA piece p of NSR is
+// issued: evenly spread, the last piece behind the tile's last group.
+__host__ __device__ constexpr int qf_piece_group(int p, int nsr, int nbf) { return 2 * nbf + ((p + 1) * 2 * nbf) / nsr - 1; }
+// pieces issued before k-step 3 starts (the counted wait for the tile's batch-operand load skips them)
+__host__ __device__ constexpr int qf_pieces_before_ks3(int nsr, int nbf) {
+    int c = 0;
+    for (int p = 0; p < nsr; p++) c += qf_piece_group(p, nsr, nbf) < 3 * nbf ? 1 : 0;
+    return c;
+}
+
 // PACKED (bit operands, LB = 1 only): the tile's last row block is the key's "remainder block" --
 // the r = rows mod 32 trailing rows, whose r*LA digit rows are packed into ONE fragment per k-step
 // (fragment row i*LA + l = digit l of trailing row i; a.rem_planes) instead of LA mostly-empty ones.
@@ -401,17 +411,142 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a, const uint32_t
     }
     QF_WAIT_AT(0, 0)
     __syncthreads();  // drains the DMA (vmcnt(0)) and synchronises the workgroup
+#ifdef QF_STAMP
+    unsigned long long s_vm = 0, s_bar = 0, s_at = 0, s_loop = 0, s_epi = 0;
+#endif
+    // ---- main loop, pinned form (bit operands and register-resident digit operands).  The key
+    // fragments of a tile are ONE stream of NF = NBF*KS reads that runs D fragments ahead of the
+    // MFMAs through a ring of D registers, across k-steps and across tiles.  hipcc cannot be
+    // trusted with it: it orders LDS reads against the LDS-DMA issues as may-alias stores (so every
+    // read that program order puts before a DMA piece bunches up in front of it), and its counted
+    // waits collapse to lgkmcnt(0) behind the loop's back edge and behind every such bunch -- four
+    // full LDS round trips per tile on both waves of a SIMD at once.  Here the reads and their
+    // counted waits are inline asm (the compiler sees neither a load nor a wait to second-guess),
+    // every group -- wait for fragment g, its MW*LB MFMAs, the read of fragment g+D into the slot
+    // just consumed, at most one DMA piece -- ends in a scheduling barrier, and
+    // check_asm_window.py proves on the ISA that nothing touches a ring register between its read
+    // and the wait that covers it.
+    constexpr bool PINNED = BITS || ATILE;
+#ifdef QF_GEMM_OLD_LOOP
+    constexpr bool USE_PINNED = false;
+#else
+    constexpr bool USE_PINNED = PINNED && MW == 1;   // MW = 2 (experiments only) has no registers for the ring
+#endif
+    // fragments in flight per wave (16 registers).  A read may reach into tile t+1 only behind tile
+    // t's mid-tile barrier (which is what guarantees that tile t+1 has landed): D <= 2*NBF.
+    constexpr int D = PF ? NBF : (NBF >= 2 ? 4 : 2);   // a whole k-step ahead where the registers allow
+    constexpr int NF = NBF * QF_KS;
+    static_assert(NF % D == 0 && D <= 2 * NBF, "ring slots must repeat per tile; reads must not pass the mid-tile barrier");
+    QF_T(tl0)
+    uint32_t buf = 0;
+    if constexpr (USE_PINNED) {
+#define QF_FRAG_OFF(fi_, ks_) ((PACKED && (fi_) == NBF - 1) ? ((WN - 1) * QF_KS * LA + (ks_)) : ((((fi_) / LA) * QF_KS + (ks_)) * LA + (fi_) % LA))
+#define QF_RD(slot_, base_, fi_, ks_)                                                             \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[slot_]) : "v"(base_), "n"(QF_FRAG_OFF(fi_, ks_) * 1024));
+        v4i ring[D];
+        v4i afb[2][MW];
+        uint32_t wsel[MW];
+        const uint32_t lds_lane = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem + (uint32_t)lane * 16;
+#pragma unroll
+        for (int g = 0; g < D; g++) QF_RD(g, lds_lane, g % NBF, g / NBF)
+        if constexpr (BITS) {
+#pragma unroll
+            for (int m = 0; m < MW; m++) {
+                const uint32_t w = (uint32_t)at[0][m][0][0];
+                afb[0][m] = qf_expand16(h ? (w >> 16) : (w & 0xFFFFu));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int P2 = qf_pieces_before_ks3(NSR, NBF);
+        for (uint32_t kt = 0; kt < ntiles; kt++) {
+            const uint32_t buf1 = buf == 2 ? 0 : buf + 1, buf2 = buf1 == 2 ? 0 : buf1 + 1;
+            const uint32_t tile = lds_lane + buf * TILE_BYTES, tile1 = lds_lane + buf1 * TILE_BYTES;
+            const uint32_t kt1 = kt + 1 < ntiles ? kt + 1 : kt;  // clamped: the tail prefetches are discarded
+            const uint32_t kt2 = kt + 2 < ntiles ? kt + 2 : ntiles - 1;
+#pragma unroll
+            for (int ks = 0; ks < QF_KS; ks++) {
+                if (ks == 2) {
+                    // mid-tile: tile t+1 has landed for everyone, tile t-1's buffer is free
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef QF_ABL_NOBAR
+                    __builtin_amdgcn_s_barrier();
+#endif
+                    QF_LOAD_AT(1, kt1)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (ks == 3) {
+                    QF_WAIT_AT(1, P2)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int fi = 0; fi < NBF; fi++) {
+                    const int g = ks * NBF + fi, slot = g % D;
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(D - 1));
+                    asm volatile("" : "+v"(ring[slot]));
+                    const int j = (PACKED && fi == NBF - 1) ? WN - 1 : fi / LA;
+                    const int l = (PACKED && fi == NBF - 1) ? 0 : fi % LA;
+#pragma unroll
+                    for (int m = 0; m < MW; m++)
+#pragma unroll
+                        for (int b = 0; b < LB; b++) {
+                            if constexpr (BITS)
+                                acc[m][j][l + b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afb[ks & 1][m], ring[slot], acc[m][j][l + b], 0, 0, 0);
+                            else
+                                acc[m][j][l + b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(at[0][m][ks * LB + b], ring[slot], acc[m][j][l + b], 0, 0, 0);
+                        }
+                    const int gn = g + D;
+#ifndef QF_ABL_NOLDS
+                    if (gn < NF) { QF_RD(slot, tile, gn % NBF, gn / NBF) }
+                    else { QF_RD(slot, tile1, (gn - NF) % NBF, (gn - NF) / NBF) }
+#endif
+#ifndef QF_ABL_NOEXP
+                    if constexpr (BITS) {
+                        // the batch operand of the NEXT k-step: 16 bits -> 16 bytes in registers, one
+                        // dword (4 VALU instructions) per group so that it never delays an MFMA
+                        if (fi == 0) {
+#pragma unroll
+                            for (int m = 0; m < MW; m++) {
+                                const uint32_t w = ks < 3 ? (uint32_t)at[0][m][0][(ks + 1) & 3] : (uint32_t)at[1][m][0][0];
+                                wsel[m] = h ? (w >> 16) : (w & 0xFFFFu);
+                            }
+                        }
+#pragma unroll
+                        for (int d = 0; d < 4; d++)
+                            if (NBF >= 4 ? fi == d : fi == 0) {
+#pragma unroll
+                                for (int m = 0; m < MW; m++)
+                                    afb[(ks + 1) & 1][m][d] = (int)((((wsel[m] >> (4 * d)) & 0xFu) * 0x00204081u) & 0x01010101u);
+                            }
+                    }
+#else
+                    if (BITS && fi == 0 && ks == 0) { _Pragma("unroll") for (int m = 0; m < MW; m++) afb[1][m] = afb[0][m]; }
+#endif
+#ifndef QF_ABL_NODMA
+                    if (ks >= 2) {
+#pragma unroll
+                        for (int p = 0; p < NSR; p++)
+                            if (qf_piece_group(p, NSR, NBF) == g) { QF_STAGE_PART(kt2, buf2, p, p + 1) }
+                    }
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < MW; m++)
+#pragma unroll
+                for (int i = 0; i < NAT; i++) at[0][m][i] = at[1][m][i];
+            buf = buf1;
+        }
+        // the reads issued for a tile past the end must not land in registers the epilogue re-uses
+        asm volatile("s_waitcnt lgkmcnt(0)");
+#pragma unroll
+        for (int g = 0; g < D; g++) asm volatile("" : "+v"(ring[g]));
+    } else {
     if constexpr (PF) {
         QF_LOAD_B(0, smem + lane * 16, 0)
         QF_LOAD_A(0, 0, 0, 0)
         __builtin_amdgcn_sched_barrier(0);
     }
-
-#ifdef QF_STAMP
-    unsigned long long s_vm = 0, s_bar = 0, s_at = 0, s_loop = 0, s_epi = 0;
-#endif
-    QF_T(tl0)
-    uint32_t buf = 0;
     for (uint32_t kt = 0; kt < ntiles; kt++) {
         const uint32_t buf1 = buf == 2 ? 0 : buf + 1, buf2 = buf1 == 2 ? 0 : buf1 + 1;
         const uint8_t *tile = smem + buf * TILE_BYTES + lane * 16;
@@ -471,6 +606,7 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a, const uint32_t
 #pragma unroll
             for (int i = 0; i < (ATILE ? NAT : 1); i++) at[0][m][i] = at[1][m][i];
         buf = buf1;
+    }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail DMAs must not outlive the workgroup's LDS
     QF_T(tl1)
@@ -571,7 +707,7 @@ __device__ __forceinline__ void qf_gemm_raster(const QfGemmArgs &a, uint32_t &bx
 }
 
 template <int LA, int LB, int WN, int MW, bool BITS>
-__global__ __launch_bounds__(QF_NW * 64, (MW * WN * (LA + LB - 1) * 16 <= 48 ? 4 : 2)) void qf_gemm_kernel(QfGemmArgs a) {
+__global__ __launch_bounds__(QF_NW * 64, (MW * WN * (LA + LB - 1) * 16 + (BITS ? 16 : 8 * QF_KS * LB) <= 72 ? 4 : 2)) void qf_gemm_kernel(QfGemmArgs a) {
     uint32_t bx, by;
     qf_gemm_raster(a, bx, by);
     qf_gemm_body<LA, LB, WN, MW, BITS, false>(a, bx, by);
