@@ -742,7 +742,7 @@ def other_workloads(args):
                     "value": world * steps / el, "unit": "hashes/s", "scaling": "weak", "steps": steps,
                     "ms_per_step": el / steps * 1e3, "dtype": "int8",
                     "config": {"workload": "SIS mat-vec n=512 m=11776, 24 keys rotated (434 MB of int8 digit planes)", "n": n, "m": m, "q": q},
-                    "roofline": {"kernel": "qf_matvec_planes_kernel<3,3>", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                    "roofline": {"kernel": "qf_matvec_planes_kernel<3,2>", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("matvec", "qf_matvec_planes") if world == 1 else None,
                                  "launch_ms": ms,
                                  "note": "algorithmic bytes = n*m*3 = 18,087,936 per hash (one launch); launch_ms = HIP events around the "
