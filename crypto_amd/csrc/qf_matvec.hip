@@ -290,81 +290,126 @@ int qf_launch_vecmat(qf_ctx *ctx, const qf_key *key, const uint32_t *x, uint32_t
     return qf_launch_vecmat_raw(ctx, key->u32, key->rows, key->cols, key->mod, x, nullptr, y);
 }
 
-// Batched decryption: a wave handles DEC_U ciphertexts per iteration (all their loads in flight
-// together), lanes stride over the n entries.  Each lane folds its split 64-bit sums to a canonical
-// residue once; the wave sum is then taken mod q with DPP adds inside each row of 16 lanes (no LDS
-// traffic) and four scalar reads.
+// Batched decryption: a wave handles DEC_U = 8 ciphertexts per iteration (all their loads in flight
+// together), lanes stride over the n entries.  The 8 per-lane sums are then reduced across the
+// wave TOGETHER by a transposing butterfly: three halving steps (lane^32, ^16, ^8: a lane keeps half
+// of its sums and receives the partner's copies of those), after which each lane owns ONE ciphertext
+// (u = lane bits 5:3), and three plain steps (^4, ^2, ^1) -- 7 + 3 exchanged values per lane instead
+// of 8 x 6, and ONE reduction mod q + decision per 8 ciphertexts instead of 8.  SINGLE: when
+// (n+1)(q-1)^2 < 2^64 the products go into one 64-bit sum per ciphertext (one v_mad_u64_u32 per
+// entry); otherwise low and high halves of the 62-bit products are summed separately.
 #define DEC_U 8
-template <int CTRL>
-__device__ __forceinline__ uint32_t dpp_addmod(uint32_t v, uint32_t q) {
-    uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
-    uint32_t s = v + o;  // both < q < 2^31
-    return min(s, s - q);
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, mask, 64);
+    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), mask, 64);
+    return ((uint64_t)hi << 32) | lo;
 }
-__device__ __forceinline__ uint32_t wave_sum_modq(uint32_t v, uint32_t q) {
-    v = dpp_addmod<0xB1>(v, q);   // quad_perm [1,0,3,2]
-    v = dpp_addmod<0x4E>(v, q);   // quad_perm [2,3,0,1]
-    v = dpp_addmod<0x141>(v, q);  // row_half_mirror: the other quad of each 8
-    v = dpp_addmod<0x140>(v, q);  // row_mirror: the other half of each row of 16
-    uint32_t r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
-    uint32_t r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
-    uint32_t a = r0 + r1; a = min(a, a - q);
-    uint32_t b = r2 + r3; b = min(b, b - q);
-    a += b;
-    return min(a, a - q);
+// v[0..7] per lane -> the wave total of v[u], u = lane bits 5:3, in every lane of that group of 8
+__device__ __forceinline__ uint64_t wave_transpose_sum8(uint64_t (&v)[DEC_U], int lane) {
+    {
+        const bool up = lane & 32;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint64_t keep = up ? v[k + 4] : v[k], give = up ? v[k] : v[k + 4];
+            v[k] = keep + shfl_xor_u64(give, 32);
+        }
+    }
+    {
+        const bool up = lane & 16;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const uint64_t keep = up ? v[k + 2] : v[k], give = up ? v[k] : v[k + 2];
+            v[k] = keep + shfl_xor_u64(give, 16);
+        }
+    }
+    const bool up = lane & 8;
+    uint64_t t = (up ? v[1] : v[0]) + shfl_xor_u64(up ? v[0] : v[1], 8);
+    t += shfl_xor_u64(t, 4);
+    t += shfl_xor_u64(t, 2);
+    t += shfl_xor_u64(t, 1);
+    return t;
 }
 // 16-byte loads that need only 4-byte alignment (ciphertext rows are 4(n+1) bytes apart: 1,028 at n = 256)
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+// One group of DEC_U ciphertexts (rows c[u]) for one wave; returns the group's residues (lane group u
+// = lane bits 5:3 holds r_u).  SINGLE also reports, wave-uniformly, whether any word of w or of the
+// ciphertexts had a bit at or above `cbits` set -- then its 64-bit sums may have wrapped and the caller redoes the
+// group with split sums.
+template <bool SINGLE>
+__device__ __forceinline__ uint32_t dec_group(const uint32_t *__restrict__ w, uint32_t n, const QfMod &mod,
+                                              const uint32_t *const (&c)[DEC_U], int lane, uint32_t cbits, bool &wide) {
+    const uint32_t nvec = n & ~3u;       // columns covered by whole 4-word groups
+    uint64_t lo[DEC_U], hi[SINGLE ? 1 : DEC_U];
+    uint32_t seen = 0;
+#pragma unroll
+    for (int u = 0; u < DEC_U; u++) {
+        lo[u] = 0;
+        if (!SINGLE) hi[u] = 0;
+    }
+#define DEC_MAD(u_, wv_, cv_) {                                                                   \
+    const uint64_t p_ = (uint64_t)(wv_) * (cv_);                                                  \
+    if (SINGLE) lo[u_] += p_; else { lo[u_] += (uint32_t)p_; hi[u_] += p_ >> 32; } }
+    // a lane takes 4 adjacent columns per step (one 16-byte load per ciphertext: a whole 1-KiB run per
+    // wave instruction, DEC_U of them in flight), the same 4 entries of w serve all DEC_U ciphertexts
+    for (uint32_t i = 4 * lane; i < nvec; i += 256) {
+        const u32x4_a4 wv = *(const u32x4_a4 *)(w + i);
+        u32x4_a4 cv[DEC_U];
+#pragma unroll
+        for (int u = 0; u < DEC_U; u++) cv[u] = *(const u32x4_a4 *)(c[u] + i);
+#pragma unroll
+        for (int u = 0; u < DEC_U; u++) {
+            DEC_MAD(u, wv.x, cv[u].x) DEC_MAD(u, wv.y, cv[u].y)
+            DEC_MAD(u, wv.z, cv[u].z) DEC_MAD(u, wv.w, cv[u].w)
+            if (SINGLE) seen |= cv[u].x | cv[u].y | cv[u].z | cv[u].w;
+        }
+        if (SINGLE) seen |= wv.x | wv.y | wv.z | wv.w;
+    }
+    // the n mod 4 trailing columns and the ciphertext's last entry c[n] (coefficient 1): lanes 0..3
+    if ((uint32_t)lane <= n - nvec) {
+        const uint32_t i = nvec + lane;              // i == n: the last entry
+        const uint32_t wt = i < n ? w[i] : 1u;
+        if (SINGLE) seen |= wt;
+#pragma unroll
+        for (int u = 0; u < DEC_U; u++) {
+            const uint32_t cvs = c[u][i];
+            DEC_MAD(u, wt, cvs)
+            if (SINGLE) seen |= cvs;
+        }
+    }
+#undef DEC_MAD
+    const uint64_t tl = wave_transpose_sum8(lo, lane);
+    if constexpr (SINGLE) {
+        wide = cbits < 32 && __any((int)((seen >> cbits) != 0));
+        return qf_red_u64(tl, mod);
+    } else {
+        wide = false;
+        const uint64_t th = wave_transpose_sum8(hi, lane);
+        return acc_finish(tl, th, mod);
+    }
+}
+// cbits > 0: one 64-bit sum per ciphertext (exact while every word of w and C is below 2^cbits: the
+// launcher has checked (n+1)(2^cbits-1)^2 < 2^64 with 2^cbits >= q, so canonical operands always
+// qualify); cbits == 0: split sums throughout.
 __global__ __launch_bounds__(256) void qf_dot_decode_kernel(const uint32_t *__restrict__ w, uint32_t n,
                                                             QfMod mod, const uint32_t *__restrict__ C,
-                                                            uint64_t B, uint8_t *__restrict__ bits) {
+                                                            uint64_t B, uint8_t *__restrict__ bits, uint32_t cbits) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint32_t stride = n + 1;
-    const uint32_t nvec = n & ~3u;       // columns covered by whole 4-word groups
     for (uint64_t b0 = wave * DEC_U; b0 < B; b0 += nwaves * DEC_U) {
         const uint32_t *c[DEC_U];
-        Acc2 acc[DEC_U];
 #pragma unroll
         for (int u = 0; u < DEC_U; u++) {
             const uint64_t b = b0 + u < B ? b0 + u : B - 1;  // clamped: the duplicate result is dropped
             c[u] = C + b * stride;
-            acc[u].lo = 0; acc[u].hi = 0;
         }
-        // a lane takes 4 adjacent columns per step (one 16-byte load per ciphertext: a whole 1-KiB run per
-        // wave instruction, DEC_U of them in flight), the same 4 entries of w serve all DEC_U ciphertexts
-        for (uint32_t i = 4 * lane; i < nvec; i += 256) {
-            const u32x4_a4 wv = *(const u32x4_a4 *)(w + i);
-            u32x4_a4 cv[DEC_U];
-#pragma unroll
-            for (int u = 0; u < DEC_U; u++) cv[u] = *(const u32x4_a4 *)(c[u] + i);
-#pragma unroll
-            for (int u = 0; u < DEC_U; u++) {
-                acc_mad(acc[u], wv.x, cv[u].x); acc_mad(acc[u], wv.y, cv[u].y);
-                acc_mad(acc[u], wv.z, cv[u].z); acc_mad(acc[u], wv.w, cv[u].w);
-            }
-        }
-        // the n mod 4 trailing columns and the ciphertext's last entry c[n] (coefficient 1): lanes 0..3
-        uint32_t last[DEC_U];
-#pragma unroll
-        for (int u = 0; u < DEC_U; u++) last[u] = 0;
-        if ((uint32_t)lane <= n - nvec) {
-            const uint32_t i = nvec + lane;              // i == n: the last entry
-            const uint32_t wt = i < n ? w[i] : 0u;
-#pragma unroll
-            for (int u = 0; u < DEC_U; u++) {
-                const uint32_t cvs = c[u][i];
-                if (i < n) acc_mad(acc[u], wt, cvs); else last[u] = cvs;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < DEC_U; u++) {
-            uint32_t r = acc_finish(acc[u].lo, acc[u].hi, mod);
-            r = qf_addmod(r, qf_red_u64(last[u], mod), mod.q);
-            r = wave_sum_modq(r, mod.q);
-            if (lane == 0 && b0 + u < B) bits[b0 + u] = (uint8_t)qf_decide_bit(r, mod);
-        }
+        bool wide = true;
+        uint32_t r = 0;
+        if (cbits) r = dec_group<true>(w, n, mod, c, lane, cbits, wide);
+        if (wide) r = dec_group<false>(w, n, mod, c, lane, cbits, wide);
+        const uint32_t u = (uint32_t)lane >> 3;
+        if ((lane & 7) == 0 && b0 + u < B) bits[b0 + u] = (uint8_t)qf_decide_bit(r, mod);
     }
 }
 int qf_launch_dot_decode(qf_ctx *ctx, const uint32_t *w, uint32_t n, const QfMod &mod, const uint32_t *C,
@@ -372,8 +417,16 @@ int qf_launch_dot_decode(qf_ctx *ctx, const uint32_t *w, uint32_t n, const QfMod
     uint64_t blocks = (B + 4 * DEC_U - 1) / (4 * DEC_U);  // 4 waves per block, DEC_U ciphertexts per wave
     if (blocks > 256 * 32) blocks = 256 * 32;
     if (blocks == 0) return QF_OK;
+    // one 64-bit sum per ciphertext is exact while (n+1) products of (2^cbits - 1)^2 stay below 2^64,
+    // cbits = bit length of q (canonical words are below 2^cbits; the kernel checks the words it reads
+    // and redoes a group with split sums if one is not)
+    uint32_t cbits = 0;
+    while ((1ull << cbits) < mod.q) cbits++;
+    const long double worst = ((long double)n + 1) * ((long double)(1ull << cbits) - 1) * ((long double)(1ull << cbits) - 1);
+    if (!(worst < 18446744073709551615.0L)) cbits = 0;
+    if (const char *e = getenv("QF_DECODE_SPLIT")) if (atoi(e)) cbits = 0;   // tests: force the split sums
     QfTimer t(ctx, &ctx->ms_decode);
-    hipLaunchKernelGGL(qf_dot_decode_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, w, n, mod, C, B, bits);
+    hipLaunchKernelGGL(qf_dot_decode_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, w, n, mod, C, B, bits, cbits);
     QF_HIP(ctx, hipGetLastError());
     return QF_OK;
 }

@@ -273,6 +273,23 @@ def test_c_abi_error_codes_and_empty_batches(ctx):
     assert b"" != lib.qf_last_error(h)
 
 
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_dot_decode_noncanonical_words_and_forced_split(ctx, monkeypatch, split):
+    """The single-sum fast path must notice operand words at or above 2^bits(q) and redo that group with
+    split sums (exact for ANY uint32 words); QF_DECODE_SPLIT=1 runs the split sums throughout."""
+    monkeypatch.setenv("QF_DECODE_SPLIT", split)
+    n, q, B = 256, 16777213, 333
+    s = co.sample_uniform(SEED, 2, 0, n, q)
+    w = ((q - s.astype(np.int64)) % q).astype(np.uint32)
+    Cm = co.sample_uniform(SEED, 9, 0, B * (n + 1), q).reshape(B, n + 1)
+    Cm[7, 3] += np.uint32(200 * q)                     # same residues, words far above q in three groups
+    Cm[100, n] += np.uint32(255 * q)
+    Cm[332, 200] = np.uint32(2 ** 32 - 1)
+    want = co.dot_decode_batch(s, q, (Cm.astype(np.uint64) % q).astype(np.uint32))
+    bits = ctx.to_host_u8(ctx.dot_decode(ctx.to_dev_u32(w), q, ctx.to_dev_u32(Cm)))
+    assert np.array_equal(bits, want)
+
+
 def test_dot_decode_ragged_and_large_n(ctx):
     """Batch sizes around the 4-ciphertexts-per-wave grouping and n that is not a multiple of 64."""
     for n, q, B in [(50, 124991, 1), (50, 124991, 5), (257, 16777213, 4099), (1000, 1073741789, 7), (3, 7, 130)]:
