@@ -202,6 +202,7 @@ int qf_launch_transpose_u32(qf_ctx *ctx, const uint32_t *src, uint32_t rows, uin
 // ---------------------------------------------------------------------------------------------
 // the GEMM
 // ---------------------------------------------------------------------------------------------
+#include <mutex>
 #include "qf_gemm.h"
 
 #ifdef QF_STAMP
@@ -735,12 +736,10 @@ template <int LA, int LB, int WN, int MW, bool BITS>
 static int qf_gemm_dispatch_wn(qf_ctx *ctx, const QfGemmArgs &args) {
     constexpr int FRAGS = WN * QF_KS * LA;
     size_t lds = 3 * (size_t)FRAGS * 1024;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static QfPerDevice attr;
+    if (attr.need(ctx->device))
         QF_HIP(ctx, hipFuncSetAttribute((const void *)qf_gemm_kernel<LA, LB, WN, MW, BITS>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
     uint64_t nmsgtiles = (args.B + 32 * QF_NW * MW - 1) / (32 * QF_NW * MW);
     dim3 grid((unsigned)nmsgtiles, (args.rb + WN - 1) / WN), block(QF_NW * 64);
     QfGemmArgs la = args;
@@ -754,11 +753,9 @@ static int qf_gemm_dispatch_wn(qf_ctx *ctx, const QfGemmArgs &args) {
 template <int LA, int WN>
 static int qf_gemm_dispatch_packed(qf_ctx *ctx, const QfGemmArgs &args) {
     size_t lds = 3 * (size_t)WN * LA * QF_KS * 1024;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static QfPerDevice attr;
+    if (attr.need(ctx->device))
         QF_HIP(ctx, hipFuncSetAttribute((const void *)qf_gemm_packed_kernel<LA, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
     uint64_t nmsgtiles = (args.B + 32 * QF_NW - 1) / (32 * QF_NW);
     dim3 grid((unsigned)nmsgtiles, args.rb / WN), block(QF_NW * 64);   // rb = full blocks + 1, a multiple of WN here
     QfGemmArgs la = args;
@@ -829,6 +826,9 @@ static int qf_gemm_dispatch(qf_ctx *ctx, const QfGemmArgs &args) {
 // builds key->fold_planes[lb] on first use (see qf_key)
 static int qf_key_fold(qf_ctx *ctx, const qf_key *key, int lb) {
     if (lb < 2 || lb > 4) return qf_fail(ctx, QF_ERR_ARG, "fold: operand digits must be 2..4");
+    // two contexts (threads) of one device may meet here with the same key: one builds, the other waits
+    static std::mutex fold_mu;
+    std::lock_guard<std::mutex> lk(fold_mu);
     if (key->fold_planes[lb]) return QF_OK;
     int8_t *planes = nullptr;
     size_t bytes = (size_t)key->rb * key->ks * lb * key->la * 1024;

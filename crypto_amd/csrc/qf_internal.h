@@ -30,6 +30,20 @@ struct qf_ctx {
     float ms_gemm = -1.f, ms_ntt = -1.f, ms_matvec = -1.f, ms_decode = -1.f;
 };
 
+// per-device "already done" flags (function attributes such as the dynamic LDS limit are per device:
+// a process that drives several GPUs must set them on each)
+#define QF_MAX_DEVICES 64
+struct QfPerDevice {
+    bool done[QF_MAX_DEVICES] = {};
+    // true exactly when the caller still has to do the work for this device (devices beyond the table: always)
+    bool need(int device) {
+        if (device < 0 || device >= QF_MAX_DEVICES) return true;
+        if (done[device]) return false;
+        done[device] = true;
+        return true;
+    }
+};
+
 struct qf_key {
     int device = 0;
     uint32_t rows = 0, cols = 0, q = 0;

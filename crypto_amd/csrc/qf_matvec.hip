@@ -148,7 +148,6 @@ __global__ __launch_bounds__(MVP_THREADS) void qf_matvec_planes_kernel(QfMvpArgs
 // with that device current) and only that pointer is ever handed to a kernel or a memset.
 #define QF_STATIC_ROWS 32768
 static __device__ __align__(256) unsigned long long qf_static_scratch[QF_STATIC_ROWS];
-#define QF_MAX_DEVICES 64
 static unsigned long long *g_static_ptr[QF_MAX_DEVICES];
 
 int qf_static_scratch_init(qf_ctx *ctx) {

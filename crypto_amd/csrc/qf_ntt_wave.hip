@@ -464,12 +464,12 @@ static int wv_launch(qf_ctx *ctx, const qf_ring *ring, const QfRingArgs &a) {
     const bool lazy = ring->q < (1u << 30);
     QfTimer t(ctx, &ctx->ms_ntt);
     if (lazy) {
-        static bool once = false;
-        if (!once) { QF_HIP(ctx, hipFuncSetAttribute((const void *)qf_ring_wave_kernel<LG, MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
+        static QfPerDevice attr;
+        if (attr.need(ctx->device)) QF_HIP(ctx, hipFuncSetAttribute((const void *)qf_ring_wave_kernel<LG, MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((qf_ring_wave_kernel<LG, MODE, true>), dim3((unsigned)blocks), dim3(WV_THREADS), lds, ctx->stream, a);
     } else {
-        static bool once = false;
-        if (!once) { QF_HIP(ctx, hipFuncSetAttribute((const void *)qf_ring_wave_kernel<LG, MODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
+        static QfPerDevice attr;
+        if (attr.need(ctx->device)) QF_HIP(ctx, hipFuncSetAttribute((const void *)qf_ring_wave_kernel<LG, MODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((qf_ring_wave_kernel<LG, MODE, false>), dim3((unsigned)blocks), dim3(WV_THREADS), lds, ctx->stream, a);
     }
     QF_HIP(ctx, hipGetLastError());

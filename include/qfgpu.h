@@ -19,10 +19,14 @@
  *   - A context is bound to one device and one stream and is not re-entrant; work is
  *     enqueued on the context's stream.  *_dev entry points are asynchronous w.r.t. the
  *     host unless stated; *_host entry points synchronise before returning.
- *   - A key handle may be shared by contexts of the same device but not used by two of them
- *     at the same time: the first product with an L-digit batch operand (L >= 2) attaches a
- *     second, L times larger set of digit planes to it (one allocation, kept until
- *     qf_key_destroy).
+ *   - Every entry point makes the device of its context (destroy calls: of the handle) current on
+ *     the calling thread and leaves it current; a host that drives several GPUs from one thread
+ *     re-selects its own device after a call if it needs to.  Kernel attributes are set up per
+ *     device, so contexts on different devices of one process are independent.
+ *   - A key handle may be shared by contexts of the same device.  The first product with an
+ *     L-digit batch operand (L >= 2) attaches a second, L times larger set of digit planes to it
+ *     (one allocation, kept until qf_key_destroy; built under a lock, so two contexts that meet
+ *     there are safe); a key must not be destroyed while any context still uses it.
  */
 #ifndef QFGPU_H
 #define QFGPU_H
