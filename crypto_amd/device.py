@@ -92,27 +92,18 @@ class Context:
     # equal and `.cpu()` has less Python around it).
     _PIN_BYTES = 1 << 20
 
-    def to_host_begin(self, t: torch.Tensor):
-        """Starts the copy of `t` to the host and returns a function that waits for it and hands out
-        the numpy array -- so that other calls can be issued while the bytes travel."""
+    def _to_host(self, t: torch.Tensor) -> np.ndarray:
         t = t.detach()
         nbytes = t.numel() * t.element_size()
         if nbytes < 4096 or nbytes > self._PIN_BYTES or not t.is_contiguous() or not t.is_cuda:
-            return lambda: t.cpu().numpy()
+            return t.cpu().numpy()
         pin = getattr(self, "_pin", None)
         if pin is None:
             pin = self._pin = torch.empty(self._PIN_BYTES, dtype=torch.uint8).pin_memory()
-        stage = pin[:nbytes].view(t.dtype).view(t.shape)
+        stage = pin[:nbytes].view(t.dtype).view(t.shape)      # one staging buffer: copy, wait, copy out
         stage.copy_(t, non_blocking=True)
-        stream = torch.cuda.current_stream(self.device)
-
-        def finish():
-            stream.synchronize()
-            return stage.numpy().copy()
-        return finish
-
-    def _to_host(self, t: torch.Tensor) -> np.ndarray:
-        return self.to_host_begin(t)()
+        torch.cuda.current_stream(self.device).synchronize()
+        return stage.numpy().copy()
 
     def to_host_u32(self, t: torch.Tensor) -> np.ndarray:
         return self._to_host(t).view(np.uint32)

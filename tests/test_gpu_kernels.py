@@ -290,6 +290,18 @@ def test_dot_decode_noncanonical_words_and_forced_split(ctx, monkeypatch, split)
     assert np.array_equal(bits, want)
 
 
+@pytest.mark.parametrize("n,q,B", [(1, 2, 9), (2, 3, 64), (4097, 2147483647, 19), (16384, 12289, 8), (255, 2147483629, 1025)])
+def test_dot_decode_extreme_moduli_and_lengths(ctx, n, q, B):
+    """Smallest and largest supported moduli, n = 1, n beyond one pass of the wave (16,384): the single-sum
+    path where (n+1)(2^bits(q)-1)^2 < 2^64, split sums beyond it; plus an empty batch."""
+    s = co.sample_uniform(SEED, 2, 0, n, q)
+    Cm = co.sample_uniform(SEED, 9, 0, B * (n + 1), q).reshape(B, n + 1)
+    w = ((q - s.astype(np.int64)) % q).astype(np.uint32)
+    bits = ctx.to_host_u8(ctx.dot_decode(ctx.to_dev_u32(w), q, ctx.to_dev_u32(Cm)))
+    assert np.array_equal(bits, co.dot_decode_batch(s, q, Cm))
+    assert ctx.dot_decode(ctx.to_dev_u32(w), q, ctx.empty_u32(0, n + 1)).numel() == 0
+
+
 def test_dot_decode_ragged_and_large_n(ctx):
     """Batch sizes around the 4-ciphertexts-per-wave grouping and n that is not a multiple of 64."""
     for n, q, B in [(50, 124991, 1), (50, 124991, 5), (257, 16777213, 4099), (1000, 1073741789, 7), (3, 7, 130)]:
