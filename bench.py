@@ -380,7 +380,7 @@ def headline(args):
                    "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"batch-shard x{world}",
                    "buffer_sets": NS, "key_broadcast_ms": t_bcast * 1e3},
         "ms_per_step_events": region_ms / args.steps, "event_pair_overhead_ms": pair_ms,
-        "roofline": {"kernel": "qf_gemm_packed_kernel<3,3> (bit operands, packed remainder row block)", "bound": "mfma",
+        "roofline": {"kernel": "qf_gemm_packedx_kernel<3,4> (bit operands; two column tiles of 4 row blocks, the packed remainder block as a 13th fragment of the last)", "bound": "mfma",
                      "achieved": achieved_tops, "peak": INT8_PEAK_TOPS, "unit": "TOP/s", "frac": achieved_tops / INT8_PEAK_TOPS,
                      "traffic": pmc_traffic("regev", "qf_gemm_") if B == 65536 else None, "launch_ms": gemm_ms,
                      "note": "int8 multiply-accumulates counted as 2 ops; algorithmic ops = 2*La*Lb*(n+1)*m per encryption x B per launch; "

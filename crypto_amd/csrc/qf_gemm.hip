@@ -246,7 +246,7 @@ __host__ __device__ constexpr int qf_pieces_before_ks3(int nsr, int nbf) {
 // rows; the epilogue gathers the LA partial sums of a row from neighbouring lanes.  Regev n = 256:
 // 257 rows cost 8*3 + 1 = 25 MFMAs per k-step and message block instead of 27.
 template <int LA, int LB, int WN, int MW, bool BITS, bool PACKED>
-__device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a, const uint32_t bx, const uint32_t by) {
+__device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a, const uint32_t bx, const uint32_t rb_first) {
     static_assert(!PACKED || (BITS && LB == 1 && MW == 1), "packed remainder block: bit operands only");
     constexpr int S = LA + LB - 1;
     constexpr int NBF = PACKED ? (WN - 1) * LA + 1 : WN * LA;   // key fragments per k-step
@@ -263,7 +263,7 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a, const uint32_t
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
-    const uint32_t rb0 = by * WN;
+    const uint32_t rb0 = rb_first;   // first row block of this column tile
     const uint64_t mb0 = ((uint64_t)bx * QF_NW + wave) * MW;  // this wave's first message block
     const uint32_t ntiles = a.ks / QF_KS;
 
@@ -435,7 +435,8 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a, const uint32_t
 #endif
     // fragments in flight per wave (16 registers).  A read may reach into tile t+1 only behind tile
     // t's mid-tile barrier (which is what guarantees that tile t+1 has landed): D <= 2*NBF.
-    constexpr int D = PF ? NBF : (NBF >= 2 ? 4 : 2);   // a whole k-step ahead where the registers allow
+    constexpr int ACCREGS = PACKED ? ((WN - 1) * S + 1) * 16 * MW : MW * WN * S * 16;
+    constexpr int D = PF ? NBF : ((NBF >= 2 && ACCREGS <= 192) ? 4 : 2);   // a whole k-step ahead where the registers allow
     constexpr int NF = NBF * QF_KS;
     static_assert(NF % D == 0 && D <= 2 * NBF, "ring slots must repeat per tile; reads must not pass the mid-tile barrier");
     QF_T(tl0)
@@ -711,15 +712,26 @@ template <int LA, int LB, int WN, int MW, bool BITS>
 __global__ __launch_bounds__(QF_NW * 64, (MW * WN * (LA + LB - 1) * 16 + (BITS ? 16 : 8 * QF_KS * LB) <= 72 ? 4 : 2)) void qf_gemm_kernel(QfGemmArgs a) {
     uint32_t bx, by;
     qf_gemm_raster(a, bx, by);
-    qf_gemm_body<LA, LB, WN, MW, BITS, false>(a, bx, by);
+    qf_gemm_body<LA, LB, WN, MW, BITS, false>(a, bx, by * WN);
 }
 // bit operands on a key with a packed remainder block: the last column tile ends with it
 template <int LA, int WN>
 __global__ __launch_bounds__(QF_NW * 64, (WN * LA * 16 <= 48 ? 4 : 2)) void qf_gemm_packed_kernel(QfGemmArgs a) {
     uint32_t bx, by;
     qf_gemm_raster(a, bx, by);
-    if (by + 1 == gridDim.y) qf_gemm_body<LA, 1, WN, 1, true, true>(a, bx, by);
-    else qf_gemm_body<LA, 1, WN, 1, true, false>(a, bx, by);
+    if (by + 1 == gridDim.y) qf_gemm_body<LA, 1, WN, 1, true, true>(a, bx, by * WN);
+    else qf_gemm_body<LA, 1, WN, 1, true, false>(a, bx, by * WN);
+}
+// the same with the remainder block as an EXTRA fragment of the last column tile: the key's full row
+// blocks split evenly into tiles of WN, the last tile computes WN blocks + the packed one (a body of
+// WN+1 "blocks", the last of them one fragment wide).  Regev n = 256: two tiles of 12 and 13 fragments
+// per k-step instead of three of 9, 9 and 7.
+template <int LA, int WN>
+__global__ __launch_bounds__(QF_NW * 64, 2) void qf_gemm_packedx_kernel(QfGemmArgs a) {
+    uint32_t bx, by;
+    qf_gemm_raster(a, bx, by);
+    if (by + 1 == gridDim.y) qf_gemm_body<LA, 1, WN + 1, 1, true, true>(a, bx, by * WN);
+    else qf_gemm_body<LA, 1, WN, 1, true, false>(a, bx, by * WN);
 }
 
 // message tiles per raster chunk (see qf_gemm_raster); QF_GEMM_MCHUNK / QF_GEMM_MCHUNK_BITS override
@@ -766,6 +778,22 @@ static int qf_gemm_dispatch_packed(qf_ctx *ctx, const QfGemmArgs &args) {
     return QF_OK;
 }
 
+template <int LA, int WN>
+static int qf_gemm_dispatch_packedx(qf_ctx *ctx, const QfGemmArgs &args) {
+    size_t lds = 3 * ((size_t)WN * LA + 1) * QF_KS * 1024;
+    static QfPerDevice attr;
+    if (attr.need(ctx->device))
+        QF_HIP(ctx, hipFuncSetAttribute((const void *)qf_gemm_packedx_kernel<LA, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    uint64_t nmsgtiles = (args.B + 32 * QF_NW - 1) / (32 * QF_NW);
+    dim3 grid((unsigned)nmsgtiles, (args.rb - 1) / WN), block(QF_NW * 64);   // rb - 1 full blocks, a multiple of WN here
+    QfGemmArgs la = args;
+    la.mchunk = qf_gemm_mchunk(true, nmsgtiles, grid.y);
+    QfTimer t(ctx, &ctx->ms_gemm);
+    hipLaunchKernelGGL((qf_gemm_packedx_kernel<LA, WN>), grid, block, lds, ctx->stream, la);
+    QF_HIP(ctx, hipGetLastError());
+    return QF_OK;
+}
+
 // Wave tile = MW*32 messages x WN*32 key rows; its accumulators (16 registers per 32x32 block and
 // digit weight) must leave room for operand fragments inside the 256-VGPR budget of 2 waves/SIMD.
 template <int LA, int LB, bool BITS>
@@ -794,6 +822,22 @@ static int qf_gemm_dispatch(qf_ctx *ctx, const QfGemmArgs &args) {
                 if (args.rb % w) continue;
                 double cost = ((double)args.rb * LA - (LA - 1)) / LA * (1.0 + 0.3 / w);
                 if (cost < bc) { bc = cost; bw = w; }
+            }
+            // ... or as an extra fragment of the last tile when the FULL blocks split evenly into tiles of
+            // w and (w*LA + 1) accumulator sets + 3 x (w*LA + 1) KiB-fragments x KS of LDS still fit
+            if constexpr (LA <= 3) if (!getenv("QF_GEMM_NOPACKX")) {   // LA = 4: 13 accumulator sets + operands do not fit
+                int xw = 0;
+                for (int w = WMAX; w >= 2; w--) {
+                    if (args.rb < 2 || (args.rb - 1) % w) continue;
+                    if ((w * LA + 1) * 16 > 208 || 3 * (w * LA + 1) * QF_KS > 160) continue;
+                    double cost = ((double)(args.rb - 1) * LA + 1) / LA * (1.0 + 0.3 / w);
+                    if (cost < bc) { bc = cost; xw = w; bw = 0; }
+                }
+                switch (xw) {
+                    case 2: if constexpr (WMAX >= 2) return qf_gemm_dispatch_packedx<LA, 2>(ctx, args); break;
+                    case 3: if constexpr (WMAX >= 3) return qf_gemm_dispatch_packedx<LA, 3>(ctx, args); break;
+                    case 4: if constexpr (WMAX >= 4) return qf_gemm_dispatch_packedx<LA, 4>(ctx, args); break;
+                }
             }
             switch (bw) {
                 case 1: return qf_gemm_dispatch_packed<LA, 1>(ctx, args);

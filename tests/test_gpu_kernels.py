@@ -474,6 +474,26 @@ def test_replay_fixtures_on_device(ctx):
     assert np.array_equal(ctx.to_host_u32(ctx.ring(n, q).polymul(ctx.to_dev_u32(a), ctx.to_dev_u32(b))), cc)
 
 
+@pytest.mark.parametrize("rows", [65, 74, 130, 194, 257, 266])
+@pytest.mark.parametrize("q", [251, 65521, 16777213])
+def test_matmul_bits_packed_remainder_as_extra_fragment(ctx, monkeypatch, rows, q):
+    """Keys whose FULL row blocks split evenly into tiles of 2..4: the packed remainder block rides as an extra
+    fragment of the last column tile (qf_gemm_packedx_kernel; Regev n = 256 is the 4 + 4 + 1 case).  Several
+    k-tiles, a partial last message tile, addend and message term; QF_GEMM_NOPACKX=1 must give the same."""
+    cols, B = 1300, 300
+    A = co.sample_uniform(SEED, 1, rows, rows * cols, q).reshape(rows, cols)
+    xb = co.sample_bits(SEED, 3, 0, B, cols, bit_stride(cols))
+    E = co.sample_uniform(SEED, 4, 0, B * rows, q).reshape(B, rows)
+    msg = co.sample_uniform(SEED, 5, 0, B, 2).astype(np.uint8)
+    key = ctx.key_upload(A, q)
+    want = co.matmul_batch(A, q, xb, co.X_BITS, B, addend=E, msg=msg)
+    out = ctx.matmul(key, ctx.to_dev_u8(xb), X_BITS, B, addend=ctx.to_dev_u32(E), msg=ctx.to_dev_u8(msg))
+    assert np.array_equal(ctx.to_host_u32(out), want)
+    monkeypatch.setenv("QF_GEMM_NOPACKX", "1")
+    out = ctx.matmul(key, ctx.to_dev_u8(xb), X_BITS, B, addend=ctx.to_dev_u32(E), msg=ctx.to_dev_u8(msg))
+    assert np.array_equal(ctx.to_host_u32(out), want)
+
+
 @pytest.mark.parametrize("rows,cols,q,B", [(33, 31, 12289, 257), (257, 17, 16777213, 300), (4, 1012, 65521, 40), (296, 253, 16777213, 65)])
 def test_matmul_bits_with_addend_on_packed_remainder(ctx, rows, cols, q, B):
     """Bit operand + addend (+ message) on keys with a packed remainder block: the remainder rows take the
