@@ -31,6 +31,31 @@ __global__ void qf_sample_bits_kernel(uint64_t base, uint64_t first_row, uint64_
     }
 }
 
+// The same rows, 16 bytes (two draws) per thread: rows whose stride is a multiple of 16 bytes in a
+// 16-byte aligned buffer (what the GEMM's bit operand requires anyway).  No 64-bit division, each draw
+// computed once, 16-byte stores: grid.x * 256 threads cover the 16-byte groups of a row, grid.y strides rows.
+__global__ __launch_bounds__(256) void qf_sample_bits16_kernel(uint64_t base, uint64_t first_row, uint64_t rows, uint32_t cols,
+                                                               uint32_t stride_bytes, uint8_t *__restrict__ out) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;       // 16-byte group of the row: bits 128g .. 128g+127
+    if (g >= stride_bytes / 16) return;
+    const uint32_t w64 = (cols + 63) / 64;
+    for (uint64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+        uint64_t v[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const uint32_t j0 = (2 * g + t) * 64;                   // first bit of this draw
+            v[t] = 0;
+            if (j0 < cols) {
+                v[t] = qf_rand64(base, (first_row + r) * w64 + 2 * g + t);
+                if (cols - j0 < 64) v[t] &= (1ull << (cols - j0)) - 1ull;   // padding bits are zero
+            }
+        }
+        uint4 o;
+        o.x = (uint32_t)v[0]; o.y = (uint32_t)(v[0] >> 32); o.z = (uint32_t)v[1]; o.w = (uint32_t)(v[1] >> 32);
+        *(uint4 *)(out + r * stride_bytes + (size_t)g * 16) = o;
+    }
+}
+
 __global__ void qf_sample_noise_kernel(uint64_t base, uint64_t first, uint64_t count, QfMod mod, uint32_t W,
                                        uint32_t *__restrict__ out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -74,6 +99,13 @@ int qf_launch_sample_uniform(qf_ctx *ctx, uint64_t base, uint64_t first, uint64_
 int qf_launch_sample_bits(qf_ctx *ctx, uint64_t base, uint64_t first_row, uint64_t rows, uint32_t cols,
                           uint32_t stride_bytes, uint8_t *out) {
     if (!rows) return QF_OK;
+    if (stride_bytes % 16 == 0 && ((uintptr_t)out & 15) == 0) {
+        const unsigned gx = (stride_bytes / 16 + 255) / 256;
+        uint64_t gy = rows < 65535 ? rows : 65535;
+        while (gy > 1 && (uint64_t)gx * gy > 256 * 64) gy = (gy + 1) / 2;     // enough waves to fill the chip, rows strided
+        hipLaunchKernelGGL(qf_sample_bits16_kernel, dim3(gx, (unsigned)gy), dim3(256), 0, ctx->stream,
+                           base, first_row, rows, cols, stride_bytes, out);
+    } else
     hipLaunchKernelGGL(qf_sample_bits_kernel, dim3(sampler_grid(rows * (stride_bytes / 4))), dim3(256), 0, ctx->stream,
                        base, first_row, rows, cols, stride_bytes, out);
     QF_HIP(ctx, hipGetLastError());

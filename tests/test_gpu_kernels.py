@@ -21,6 +21,15 @@ def test_sampler_matches_oracle(ctx):
     assert np.array_equal(d, co.sample_bits(SEED, 3, 11, 37, 867, st))
 
 
+@pytest.mark.parametrize("rows,cols,stride", [(1, 1, 16), (3, 64, 16), (5, 65, 32), (70000, 129, 32), (300, 6168, 784), (9, 867, 116),
+                                              (2, 4096, 512), (4, 127, 20)])
+def test_sample_bits_both_kernels(ctx, rows, cols, stride):
+    """Bit rows: the 16-bytes-per-thread kernel (strides that are multiples of 16: the GEMM's operand layout)
+    and the dword kernel (other strides), draw boundaries at 64/128 bits, more rows than grid.y can hold."""
+    d = ctx.to_host_u8(ctx.sample_bits(SEED, 3, 5, rows, cols, stride))
+    assert np.array_equal(d, co.sample_bits(SEED, 3, 5, rows, cols, stride))
+
+
 @pytest.mark.parametrize("rows,cols,q", [(14, 154, 1427), (51, 867, 124991), (257, 6168, 16777213),
                                           (1, 3, 7), (33, 4097, 1073741789), (5, 18, 11)])
 def test_matvec_vecmat(ctx, rows, cols, q):
