@@ -564,6 +564,25 @@ def other_workloads(args):
                                  "traffic": pmc_traffic("lpr", "qf_gemm_kernel") if world == 1 else None, "launch_ms": gemm_ms,
                                  "whole_call_ms": ms, "hbm_frac_whole_call": gbs / HBM_PEAK_GBS,
                                  "note": "algorithmic int8 ops = 2*4*2*(n+1)*n per encryption (SURVEY 8d's 2.52e7 assumes 3 operand digits)"}})
+        # the decryption half of config 4: <[-s ; 1], c> + decision rule over the ciphertexts just written
+        # (1.07 GB per 262,144: far beyond the Infinity Cache, so the read is HBM-cold by size)
+        w_dec = ctx.sample_uniform(SEED, 2, 0, n, q)
+        bits_dec = ctx.empty_u8(B)
+        for _ in range(3):
+            ctx.dot_decode(w_dec, q, c, out=bits_dec)
+        ctx.set_timing(True)
+        dms = []
+        for _ in range(max(3, min(args.steps, 20))):
+            ctx.dot_decode(w_dec, q, c, out=bits_dec)
+            dms.append(ctx.last_kernel_ms("decode"))
+        ctx.set_timing(False)
+        dec_ms = float(np.mean(dms))
+        dec_gbs = B * 4 * (n + 1) / (dec_ms * 1e-3) / 1e9
+        out["decode"] = {"kernel": "qf_dot_decode_kernel (split sums: (n+1) q^2 > 2^64)", "bound": "hbm", "launch_ms": dec_ms, "achieved": dec_gbs,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dec_gbs / HBM_PEAK_GBS,
+                         "decryptions_per_s": B * world / (dec_ms * 1e-3),
+                         "enc_dec_round_trips_per_s": B * world / ((el / args.steps) + dec_ms * 1e-3),
+                         "note": "lpr.rs:454-468 on the batch; algorithmic bytes = 4(n+1) per ciphertext"}
         if want_cpu:
             pk_h = ctx.to_host_u32(pk)
             threads = co.num_threads()
@@ -598,6 +617,22 @@ def other_workloads(args):
             bytes_per = 5 * 4 * n + n // 8
             kname, kpre = "qf_ring_wave_kernel<10,rlpr_enc,lazy>", "qf_ring_wave_kernel<10, 1"
             out.update({"metric": "RingLPR encryptions/sec (= 2 ring products each)", "value": Btot * args.steps / el, "unit": "encryptions/s"})
+            # the decryption half (ring_lpr.rs:491-507): v - s*u, threshold, bit packing -- one launch
+            sk_ring = ring.key(ctx.sample_noise(SEED, 2, 0, n, q, W).view(1, n))
+            mu_out = ctx.empty_u8(B, n // 8)
+            for _ in range(3):
+                ring.ringlpr_dec(sk_ring, u, v, out=mu_out)
+            ctx.set_timing(True)
+            dms = []
+            for _ in range(max(3, min(args.steps, 20))):
+                ring.ringlpr_dec(sk_ring, u, v, out=mu_out)
+                dms.append(ctx.last_kernel_ms("ntt"))
+            ctx.set_timing(False)
+            dec_ms = float(np.mean(dms))
+            dec_gbs = B * (8 * n + n // 8) / (dec_ms * 1e-3) / 1e9
+            out["decrypt"] = {"kernel": "qf_ring_wave_kernel<10,rlpr_dec,lazy>", "bound": "hbm", "launch_ms": dec_ms, "achieved": dec_gbs,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dec_gbs / HBM_PEAK_GBS, "decryptions_per_s": B * world / (dec_ms * 1e-3),
+                              "note": "algorithmic bytes = 8n + n/8 per ciphertext (u, v in; n message bits out)"}
             if want_cpu:
                 k_h = ctx.to_host_u32(keys)
                 threads = co.num_threads()
