@@ -239,6 +239,14 @@ __host__ __device__ constexpr int qf_pieces_before_ks3(int nsr, int nbf) {
     return c;
 }
 
+// 16x16x64 body: a tile is G = 2H groups; the NSR LDS-DMA pieces go behind groups of its second half
+__host__ __device__ constexpr int qf16_piece_group(int p, int nsr, int h) { return h + ((p + 1) * h) / nsr - 1; }
+__host__ __device__ constexpr int qf16_pieces_before(int nsr, int h, int g) {
+    int c = 0;
+    for (int p = 0; p < nsr; p++) c += qf16_piece_group(p, nsr, h) < g ? 1 : 0;
+    return c;
+}
+
 // PACKED (bit operands, LB = 1 only): the tile's last row block is the key's "remainder block" --
 // the r = rows mod 32 trailing rows, whose r*LA digit rows are packed into ONE fragment per k-step
 // (fragment row i*LA + l = digit l of trailing row i; a.rem_planes) instead of LA mostly-empty ones.
@@ -690,6 +698,246 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a, const uint32_t
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// Bit operands on v_mfma_i32_16x16x64_i8 (round 2).  Same tiles, same HBM and LDS images, same
+// LDS-DMA pipeline as qf_gemm_body's pinned loop -- only the matrix instruction changes: a 32x32
+// output block over 64 columns is four 16x16x64 MFMAs (two message halves x two row halves)
+// instead of two 32x32x32.  The chip holds ~2.3 GHz under 16x16x64 where it drops to 1.7-1.8 GHz
+// under 32x32x32 on the same operands (tools/ubench_mfma.hip), and the full kernel is 14-16 %
+// faster for it.  Nothing is re-laid-out: lane l of a 16x16x64 operand wants row (l & 15), columns
+// 16*(l >> 4) .. +15 of the 64 -- the SAME 16-byte chunk some lane of a 32x32x32 fragment holds
+// (rows 16*half + (l & 15), k-half (l >> 4) & 1, of k-step 2*s' + (l >> 5)) -- so every lane
+// simply reads a different chunk of the 1-KiB fragment images, and the bits of a message row are
+// expanded per 16-message half.
+template <int LA, int WN, int PK>
+__device__ __forceinline__ void qf_gemm_body16(const QfGemmArgs &a, const uint32_t bx, const uint32_t rb_first) {
+    constexpr bool PACKED = PK != 0;
+    constexpr bool PK16 = PK == 2;      // the packed block's r*LA digit rows all lie in its first 16: no second row half
+    constexpr int S = LA;                                       // one operand digit
+    constexpr int NBF = PACKED ? (WN - 1) * LA + 1 : WN * LA;   // key fragments per 32-wide k-step
+    constexpr int FRAGS = NBF * QF_KS;
+    constexpr int TILE_BYTES = FRAGS * 1024;
+    constexpr int NSR = (FRAGS + QF_NW - 1) / QF_NW;
+    constexpr int H = 2 * NBF - (PK16 ? 1 : 0);                 // groups per k-step of 64: NBF fragments x 2 row halves
+    constexpr int G = 2 * H;                                    // groups (= LDS reads) per k-tile
+    constexpr int ACCREGS = (PACKED ? (WN - 1) * S * 16 + (PK16 ? 8 : 16) : WN * S * 16);
+    constexpr int D0 = (NBF >= 2 && ACCREGS < 192 && !PK16) ? 4 : 2;   // chunks in flight (ring registers / 4)
+    constexpr int D = D0 <= G / 2 ? D0 : G / 2;
+    static_assert(G % D == 0 && D <= G / 2, "ring slots repeat per tile; reads must not pass the mid-tile barrier");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 3 * TILE_BYTES
+
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const uint32_t rb0 = rb_first;
+    const uint64_t mb0 = (uint64_t)bx * QF_NW + wave;           // this wave's message block (32 messages)
+    const uint32_t ntiles = a.ks / QF_KS;
+    uint32_t msgmask = 0;             // message bits of the wave's 32 messages (bit = message row inside the block)
+
+    v4i acc[2][WN][2][S];             // [message half][row block][row half][digit]
+    {   // ---- main part (its lane-derived values end with it)
+    const int lane = (int)threadIdx.x & 63;
+    const int lc = lane & 15;         // row inside a group of 16 (message row as A, key row as B / D column)
+    const int lq = lane >> 4;         // k-quarter this lane feeds; message quarter (4 rows) it receives
+#pragma unroll
+    for (int mg = 0; mg < 2; mg++)
+#pragma unroll
+        for (int j = 0; j < WN; j++)
+#pragma unroll
+            for (int kg = 0; kg < 2; kg++)
+#pragma unroll
+                for (int s = 0; s < S; s++) acc[mg][j][kg][s] = v4i{0, 0, 0, 0};
+
+    // batch operand: the 128 bits per k-tile of message rows 16*mg + lc (inline-asm loads, see QF_LOAD_AT),
+    // addressed as (uniform base of the workgroup's first message row) + (32-bit per-lane offset)
+    const uint64_t tile_row0 = (uint64_t)bx * QF_NW * 32;
+    const uint8_t *xbase = a.xbits + (tile_row0 < a.B ? tile_row0 : a.B - 1) * a.xstride;
+    uint32_t xoff[2];
+#pragma unroll
+    for (int mg = 0; mg < 2; mg++) {
+        const uint64_t mrow_l = mb0 * 32 + 16 * mg + lc;
+        const uint64_t mrow_c = mrow_l < a.B ? mrow_l : a.B - 1;
+        xoff[mg] = (uint32_t)((mrow_c - (tile_row0 < a.B ? tile_row0 : a.B - 1)) * a.xstride);   // < 256 rows
+    }
+    v4i at[2][2];
+#define QF16_LOAD_AT(set_, kt_)                                                                   \
+    _Pragma("unroll") for (int mg_ = 0; mg_ < 2; mg_++) {                                         \
+        size_t off_ = (size_t)(kt_)*16;                                                           \
+        off_ = off_ + 16 <= a.xstride ? off_ : a.xstride - 16;                                    \
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(at[set_][mg_]) : "v"(xoff[mg_] + (uint32_t)off_), "s"(xbase) : "memory"); \
+    }
+#define QF16_WAIT_AT(set_, n_)                                                                    \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory");                                     \
+    asm volatile("" : "+v"(at[set_][0]));                                                         \
+    asm volatile("" : "+v"(at[set_][1]));
+    // 16 bits -> 16 bytes for k-step sp (of 64) of the tile whose words are in at[set_][mg_]: the lane's
+    // bits are half (lq & 1) of dword 2*sp + (lq >> 1)
+#define QF16_WSEL(set_, mg_, sp_) {                                                               \
+        const uint32_t w_ = (lq >> 1) ? (uint32_t)at[set_][mg_][2 * (sp_) + 1] : (uint32_t)at[set_][mg_][2 * (sp_)]; \
+        wsel[mg_] = (lq & 1) ? (w_ >> 16) : (w_ & 0xFFFFu); }
+#define QF16_EXPAND(dst_, mg_, d_) dst_[d_] = (int)((((wsel[mg_] >> (4 * (d_))) & 0xFu) * 0x00204081u) & 0x01010101u);
+
+    QF16_LOAD_AT(0, 0)
+    QF_STAGE(0, 0)
+    QF_STAGE(ntiles > 1 ? 1 : 0, 1)
+    if (a.msg && (uint64_t)(rb0 + WN) * 32 >= a.rows) {
+        const uint64_t mrow_l = mb0 * 32 + (lane & 31);
+        const bool bit = lane < 32 && mrow_l < a.B && (a.msg[mrow_l < a.B ? mrow_l : 0] & 1);
+        msgmask = (uint32_t)__ballot(bit);
+    }
+    QF16_WAIT_AT(0, 0)
+    __syncthreads();  // drains the DMA (vmcnt(0)) and synchronises the workgroup
+
+    // per-lane chunk of a fragment image: row lc (+16 per row half, in the read's immediate offset),
+    // k-half (lq & 1), of k-step 2*sp + (lq >> 1) -- consecutive k-steps of a fragment are LA KiB apart
+    // (1 KiB in the packed block)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
+    const uint32_t laneA = lds0 + (uint32_t)(lc + 32 * (lq & 1)) * 16 + (uint32_t)(lq >> 1) * LA * 1024;
+    const uint32_t laneP = lds0 + (uint32_t)(lc + 32 * (lq & 1)) * 16 + (uint32_t)(lq >> 1) * 1024;
+#define QF16_OFF(fi_, sp_, kg_) (((PACKED && (fi_) == NBF - 1) ? ((WN - 1) * QF_KS * LA + 2 * (sp_)) : ((((fi_) / LA) * QF_KS + 2 * (sp_)) * LA + (fi_) % LA)) * 1024 + (kg_) * 256)
+    // group g of a tile -> k-step of 64 (g / H), fragment ((g % H) / 2) and row half ((g % H) % 2)
+#define QF16_RD(slot_, tA_, tP_, g_)                                                              \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[slot_])                              \
+                 : "v"((PACKED && ((g_) % H) / 2 == NBF - 1) ? (tP_) : (tA_)),                    \
+                   "n"(QF16_OFF(((g_) % H) / 2, (g_) / H, ((g_) % H) % 2)));
+    v4i ring[D];
+    v4i afb[2][2];                    // [k-step of 64 (parity)][message half]
+    uint32_t wsel[2];
+#pragma unroll
+    for (int g = 0; g < D; g++) QF16_RD(g, laneA, laneP, g)
+#pragma unroll
+    for (int mg = 0; mg < 2; mg++) {
+        QF16_WSEL(0, mg, 0)
+#pragma unroll
+        for (int d = 0; d < 4; d++) QF16_EXPAND(afb[0][mg], mg, d)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // group of the tile's second k-step behind which the next tile's bits are waited for and expanded
+    constexpr int WPOS = H + NBF < G ? H + NBF : G - 1;
+    constexpr bool SPREAD = (WPOS - H) + 10 <= H;   // one expansion piece per group (10 pieces per k-step of 64), else all at once
+    uint32_t buf = 0;
+    for (uint32_t kt = 0; kt < ntiles; kt++) {
+        const uint32_t buf1 = buf == 2 ? 0 : buf + 1, buf2 = buf1 == 2 ? 0 : buf1 + 1;
+        const uint32_t tA = laneA + buf * TILE_BYTES, tP = laneP + buf * TILE_BYTES;
+        const uint32_t kt1 = kt + 1 < ntiles ? kt + 1 : kt;  // clamped: the tail prefetches are discarded
+        const uint32_t kt2 = kt + 2 < ntiles ? kt + 2 : ntiles - 1;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int sp = g / H, rem = g % H, fi = rem / 2, kg = rem % 2, slot = g % D;
+            if (g == H) {
+                // mid-tile: tile t+1 has landed for everyone, tile t-1's buffer is free
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                QF16_LOAD_AT(1, kt1)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (g == WPOS) {
+                // the next tile's bits: all but the DMA pieces issued behind the load have retired
+                constexpr int P2 = qf16_pieces_before(NSR, H, WPOS);
+                QF16_WAIT_AT(1, P2)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(D - 1));
+            asm volatile("" : "+v"(ring[slot]));
+            const int j = (PACKED && fi == NBF - 1) ? WN - 1 : fi / LA;
+            const int l = (PACKED && fi == NBF - 1) ? 0 : fi % LA;
+#pragma unroll
+            for (int mg = 0; mg < 2; mg++)
+                acc[mg][j][kg][l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afb[sp][mg], ring[slot], acc[mg][j][kg][l], 0, 0, 0);
+            const int gn = g + D;
+            if (gn < G) { QF16_RD(slot, tA, tP, gn) }
+            else { QF16_RD(slot, laneA + buf1 * TILE_BYTES, laneP + buf1 * TILE_BYTES, gn - G) }   // the next tile's first chunks
+            // the operand of the NEXT k-step of 64 (sp = 0: this tile's second; sp = 1, behind the counted
+            // wait: the next tile's first): per message half one word select + four dword expansions
+            {
+                const int e0 = sp == 0 ? 0 : WPOS - H;
+#pragma unroll
+                for (int mg = 0; mg < 2; mg++) {
+                    if (SPREAD ? rem == e0 + 5 * mg : rem == e0) {
+                        if (sp == 0) { QF16_WSEL(0, mg, 1) } else { QF16_WSEL(1, mg, 0) }
+                    }
+#pragma unroll
+                    for (int d = 0; d < 4; d++)
+                        if (SPREAD ? rem == e0 + 5 * mg + 1 + d : rem == e0) { QF16_EXPAND(afb[sp ^ 1][mg], mg, d) }
+                }
+            }
+            if (g >= H) {
+#pragma unroll
+                for (int p = 0; p < NSR; p++)
+                    if (qf16_piece_group(p, NSR, H) == g) { QF_STAGE_PART(kt2, buf2, p, p + 1) }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        at[0][0] = at[1][0];
+        at[0][1] = at[1][1];
+        buf = buf1;
+    }
+    // the reads issued for a tile past the end must not land in registers the epilogue re-uses
+    asm volatile("s_waitcnt lgkmcnt(0)");
+#pragma unroll
+    for (int g = 0; g < D; g++) asm volatile("" : "+v"(ring[g]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail DMAs must not outlive the workgroup's LDS
+    }
+
+    // ---- epilogue.  D tile of a 16x16x64 MFMA: lane holds key row 16*kg + lc of the block, messages
+    // 16*mg + 4*lq + r (r = register 0..3).  The lane index is re-derived here (mbcnt, opaque to the
+    // compiler): otherwise hipcc computes the epilogue's per-lane addresses in front of the main loop
+    // and keeps them alive -- or spills them -- across it.
+    uint32_t lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const int lane = (int)lane_e, lc = lane & 15, lq = lane >> 4;
+    const uint32_t lastrow = a.rows - 1;
+#pragma unroll
+    for (int mg = 0; mg < 2; mg++) {
+#pragma unroll
+    for (int j = 0; j < WN; j++) {
+        if (PACKED && j == WN - 1) {
+            // remainder block: fragment row p = i*LA + l holds digit l of trailing row i, i.e. it sits in row
+            // half p >> 4 at lane column p & 15 (same message quarter).  Lane column c serves trailing rows
+            // c and c + 16: it gathers their LA digits from the lanes that hold them.
+#pragma unroll
+            for (int hh = 0; hh < (PK16 ? 1 : 2); hh++) {
+                const uint32_t ir = (uint32_t)lc + 16 * hh;
+                const uint32_t krow = (rb0 + j) * 32 + ir;
+                const bool owner = ir < a.rem_rows;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint64_t mrow = mb0 * 32 + 16 * mg + 4 * lq + r;
+                    int64_t x = 0;
+#pragma unroll
+                    for (int l = 0; l < LA; l++) {
+                        const uint32_t pp = (ir * LA + l) & 31;          // rows beyond the block: masked, never owners
+                        const int src = (int)((pp & 15) | (uint32_t)(lane & 48));
+                        int v = __shfl(acc[mg][j][0][0][r], src, 64);
+                        if constexpr (!PK16) { const int v1 = __shfl(acc[mg][j][1][0][r], src, 64); v = (pp >> 4) ? v1 : v; }
+                        x += (int64_t)v * (int64_t)a.cs[l];
+                    }
+                    if (!owner || mrow >= a.B) continue;
+                    if (a.addend) x += (int64_t)a.addend[mrow * a.rows + krow];
+                    if (krow == lastrow && ((msgmask >> (16 * mg + 4 * lq + r)) & 1)) x += (int64_t)a.mod.qhalf;
+                    a.out[mrow * a.rows + krow] = qf_red_i64(x, a.mod);
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int kg = 0; kg < 2; kg++) {
+            const uint32_t krow = (rb0 + j) * 32 + 16 * kg + lc;
+            if (rb0 + j >= a.rb || krow >= a.rows) continue;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint64_t mrow = mb0 * 32 + 16 * mg + 4 * lq + r;
+                if (mrow >= a.B) continue;
+                int64_t x = 0;
+#pragma unroll
+                for (int s = 0; s < S; s++) x += (int64_t)acc[mg][j][kg][s][r] * (int64_t)a.cs[s];
+                if (a.addend) x += (int64_t)a.addend[mrow * a.rows + krow];
+                if (krow == lastrow && ((msgmask >> (16 * mg + 4 * lq + r)) & 1)) x += (int64_t)a.mod.qhalf;
+                a.out[mrow * a.rows + krow] = qf_red_i64(x, a.mod);
+            }
+        }
+    }
+    }
+}
+
 // Raster order.  Plain: workgroups run message-tile-fastest, so one column tile's key planes stay
 // in L2 while the whole batch streams by -- and the batch operand is re-read from HBM once per
 // column tile.  With a.mchunk set, CHUNKS of a.mchunk message tiles run through every column tile
@@ -712,6 +960,10 @@ template <int LA, int LB, int WN, int MW, bool BITS>
 __global__ __launch_bounds__(QF_NW * 64, (MW * WN * (LA + LB - 1) * 16 + (BITS ? 16 : 8 * QF_KS * LB) <= 72 ? 4 : 2)) void qf_gemm_kernel(QfGemmArgs a) {
     uint32_t bx, by;
     qf_gemm_raster(a, bx, by);
+#ifndef QF_GEMM_MFMA32
+    if constexpr (BITS && MW == 1 && LB == 1) qf_gemm_body16<LA, WN, 0>(a, bx, by * WN);
+    else
+#endif
     qf_gemm_body<LA, LB, WN, MW, BITS, false>(a, bx, by * WN);
 }
 // bit operands on a key with a packed remainder block: the last column tile ends with it
@@ -719,8 +971,15 @@ template <int LA, int WN>
 __global__ __launch_bounds__(QF_NW * 64, (WN * LA * 16 <= 48 ? 4 : 2)) void qf_gemm_packed_kernel(QfGemmArgs a) {
     uint32_t bx, by;
     qf_gemm_raster(a, bx, by);
+#ifndef QF_GEMM_MFMA32
+    if (by + 1 == gridDim.y) {
+        if (a.rem_rows * LA <= 16) qf_gemm_body16<LA, WN, 2>(a, bx, by * WN);
+        else qf_gemm_body16<LA, WN, 1>(a, bx, by * WN);
+    } else qf_gemm_body16<LA, WN, 0>(a, bx, by * WN);
+#else
     if (by + 1 == gridDim.y) qf_gemm_body<LA, 1, WN, 1, true, true>(a, bx, by * WN);
     else qf_gemm_body<LA, 1, WN, 1, true, false>(a, bx, by * WN);
+#endif
 }
 // the same with the remainder block as an EXTRA fragment of the last column tile: the key's full row
 // blocks split evenly into tiles of WN, the last tile computes WN blocks + the packed one (a body of
@@ -730,8 +989,13 @@ template <int LA, int WN>
 __global__ __launch_bounds__(QF_NW * 64, 2) void qf_gemm_packedx_kernel(QfGemmArgs a) {
     uint32_t bx, by;
     qf_gemm_raster(a, bx, by);
+#ifndef QF_GEMM_MFMA32
+    if (by + 1 == gridDim.y) qf_gemm_body16<LA, WN + 1, 2>(a, bx, by * WN);   // dispatched only when rem_rows*LA <= 16
+    else qf_gemm_body16<LA, WN, 0>(a, bx, by * WN);
+#else
     if (by + 1 == gridDim.y) qf_gemm_body<LA, 1, WN + 1, 1, true, true>(a, bx, by * WN);
     else qf_gemm_body<LA, 1, WN, 1, true, false>(a, bx, by * WN);
+#endif
 }
 
 // message tiles per raster chunk (see qf_gemm_raster); QF_GEMM_MCHUNK / QF_GEMM_MCHUNK_BITS override
@@ -829,6 +1093,9 @@ static int qf_gemm_dispatch(qf_ctx *ctx, const QfGemmArgs &args) {
                 int xw = 0;
                 for (int w = WMAX; w >= 2; w--) {
                     if (args.rb < 2 || (args.rb - 1) % w) continue;
+#ifndef QF_GEMM_MFMA32
+                    if (args.rem_rows * LA > 16) continue;   // the 16x16x64 body keeps only the first row half of the extra fragment
+#endif
                     if ((w * LA + 1) * 16 > 208 || 3 * (w * LA + 1) * QF_KS > 160) continue;
                     double cost = ((double)(args.rb - 1) * LA + 1) / LA * (1.0 + 0.3 / w);
                     if (cost < bc) { bc = cost; xw = w; bw = 0; }

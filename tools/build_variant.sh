@@ -10,7 +10,7 @@ for f in qf_api qf_gemm qf_matvec qf_ntt qf_ntt_wave qf_sampler qf_sha256; do
   [ $f = qf_ntt_wave ] && flags="$*"
   rem=""
   [ $f = qf_gemm ] && rem="-Rpass-analysis=kernel-resource-usage"
-  /opt/rocm/bin/hipcc $flags $rem -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -c $root/crypto_amd/csrc/$f.hip -o $tmp/$f.o 2> $tmp/$f.remarks &
+  /opt/rocm/bin/hipcc $flags $rem -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -c $root/crypto_amd/csrc/$f.hip -mllvm -pragma-unroll-threshold=262144 -o $tmp/$f.o 2> $tmp/$f.remarks &
 done
 wait
 # a GEMM kernel that spills must never run (see crypto_amd/csrc/Makefile): the NOLDS variant of the
