@@ -380,7 +380,7 @@ def headline(args):
                    "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"batch-shard x{world}",
                    "buffer_sets": NS, "key_broadcast_ms": t_bcast * 1e3},
         "ms_per_step_events": region_ms / args.steps, "event_pair_overhead_ms": pair_ms,
-        "roofline": {"kernel": "qf_gemm_packedx_kernel<3,4> (bit operands; two column tiles of 4 row blocks, the packed remainder block as a 13th fragment of the last)", "bound": "mfma",
+        "roofline": {"kernel": "qf_gemm_packedx_kernel<3,4> (bit operands on v_mfma_i32_16x16x64_i8; two column tiles of 4 row blocks, the packed remainder block as a 13th fragment of the last)", "bound": "mfma",
                      "achieved": achieved_tops, "peak": INT8_PEAK_TOPS, "unit": "TOP/s", "frac": achieved_tops / INT8_PEAK_TOPS,
                      "traffic": pmc_traffic("regev", "qf_gemm_") if B == 65536 else None, "launch_ms": gemm_ms,
                      "note": "int8 multiply-accumulates counted as 2 ops; algorithmic ops = 2*La*Lb*(n+1)*m per encryption x B per launch; "
@@ -492,7 +492,7 @@ def other_workloads(args):
                     "ms_per_step": el / args.steps * 1e3, "dtype": "int8",
                     "config": {"workload": "SIS hash, binary inputs (BASELINE config 3)", "n": n, "m": m, "q": q, "global_batch": Btot,
                                "key_broadcast_ms": bcast["s"] * 1e3},
-                    "roofline": {"kernel": "qf_gemm_kernel<3,1,4,1,bits>", "bound": "mfma", "achieved": tops, "peak": INT8_PEAK_TOPS,
+                    "roofline": {"kernel": "qf_gemm_kernel<3,1,4,1,bits> (v_mfma_i32_16x16x64_i8)", "bound": "mfma", "achieved": tops, "peak": INT8_PEAK_TOPS,
                                  "unit": "TOP/s", "frac": tops / INT8_PEAK_TOPS, "traffic": pmc_traffic("sis", "qf_gemm_kernel<3, 1, 4, 1, true>") if world == 1 else None,
                                  "launch_ms": ms, "note": "algorithmic int8 ops = 2*3*n*m per hash x B per launch; one launch per step"}})
         # secondary: inputs uniform in Z_q (hash/sis.rs:46), B = 2^16: recode to 3 digits + GEMM

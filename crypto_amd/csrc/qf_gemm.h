@@ -21,6 +21,8 @@ struct QfGemmArgs {
     uint32_t *out;           // B x rows
     QfMod mod;
     int32_t cs[8];           // centred 2^(8s) mod q
+    double qd, qinv;         // q and 1/q as doubles (fp64 epilogue of the one-digit kernels)
+    uint32_t epi2;           //   1: reduce the upper digit pair before recombining (see qf_epi_f64)
     unsigned long long *dbg; // diagnostic build only (QF_STAMP): per-wave cycle sums
 };
 
@@ -34,4 +36,30 @@ __device__ __forceinline__ v4i qf_expand16(uint32_t w16) {
     return r;
 }
 
-
+// Epilogue arithmetic of the one-digit-operand kernels (LB = 1: every BASELINE shape), in fp64: the
+// int64 version costs 9 quarter-rate 64-bit multiply-adds per element (4 to recombine, 3 in the
+// Barrett reduction, 2 for the address) and made the epilogue a third of the LPR launch.
+//   x = a0 + 256 a1 + 65536 (a2 + 256 a3) + extra     exact in a double: the host guarantees
+//       |x| < 2^52, or sets epi2 and the upper pair is reduced mod q first (|65536 hi'| < 2^47);
+//   t = rint(x / q), r = x - t q                        one fma, exact: an integer, |r| <= q/2 + 1/4;
+//   result = r < 0 ? r + q : r                          in 32-bit integers.
+// Signed digits represent an entry EXACTLY (sum d_s 256^s = its representative), so the true powers
+// of 256 are used here, not the centred residues cs[].
+template <int S>
+__device__ __forceinline__ uint32_t qf_epi_f64(int a0, int a1, int a2, int a3, double extra, const QfGemmArgs &a) {
+    static_assert(S >= 1 && S <= 4, "one-digit operands: S = LA <= 4");
+    double x = (double)a0 + extra;
+    if constexpr (S >= 2) x = __builtin_fma((double)a1, 256.0, x);
+    if constexpr (S >= 3) {
+        double hi = (double)a2;
+        if constexpr (S >= 4) hi = __builtin_fma((double)a3, 256.0, hi);
+        if (a.epi2) {
+            asm volatile("");   // a real (uniform) branch: hipcc would otherwise compute this and select
+            hi = __builtin_fma(-__builtin_rint(hi * a.qinv), a.qd, hi);
+        }
+        x = __builtin_fma(hi, 65536.0, x);
+    }
+    const double t = __builtin_rint(x * a.qinv);
+    const int r = (int)__builtin_fma(-t, a.qd, x);
+    return (uint32_t)r + ((uint32_t)(r >> 31) & a.mod.q);
+}

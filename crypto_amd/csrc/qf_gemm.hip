@@ -421,7 +421,7 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a, const uint32_t
     QF_WAIT_AT(0, 0)
     __syncthreads();  // drains the DMA (vmcnt(0)) and synchronises the workgroup
 #ifdef QF_STAMP
-    unsigned long long s_vm = 0, s_bar = 0, s_at = 0, s_loop = 0, s_epi = 0;
+    unsigned long long s_vm = 0, s_bar = 0, s_at = 0, s_loop = 0, s_epi = 0, s_eld = 0, s_ecomp = 0, s_edrain = 0;
 #endif
     // ---- main loop, pinned form (bit operands and register-resident digit operands).  The key
     // fragments of a tile are ONE stream of NF = NBF*KS reads that runs D fragments ahead of the
@@ -622,8 +622,15 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a, const uint32_t
     QF_T(tl1)
     QF_ACC(s_loop, tl0, tl1)
 
-    // ---- epilogue: recombine digits, reduce, add noise / message, store
+    // ---- epilogue: recombine digits, reduce, add noise / message, store.  The lane index is re-derived
+    // (mbcnt, opaque to the compiler) so that none of the per-lane offsets is computed in front of the
+    // main loop and kept alive across it.
     const uint32_t lastrow = a.rows - 1;
+    uint32_t lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const uint32_t he = lane_e >> 5;
+    const uint32_t rowbytes = a.rows * 4;
+    const uint32_t voff_st = 4 * he * rowbytes + (lane_e & 31) * 4;                    // byte offset of (message 4h, column lane & 31)
 #pragma unroll
     for (int i = 0; i < MW; i++) {
 #pragma unroll
@@ -648,52 +655,105 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a, const uint32_t
             }
             continue;
         }
-        const uint32_t krow = (rb0 + j) * 32 + (lane & 31);
+        const uint32_t krow = (rb0 + j) * 32 + (lane_e & 31);
         if (rb0 + j >= a.rb || krow >= a.rows) continue;
-        // addend: all 16 loads of the row block in flight at once (clamped addresses, no branch around
-        // them -- behind the per-element bounds branch every load was waited for on its own: LPR
-        // n=1024 2.9 -> 2.5 ms).  The packed kernels have no registers to spare for that and keep one
-        // load per element.
-        constexpr bool BATCH = !PACKED;
-        uint32_t add[BATCH ? 16 : 1];
-        const bool late_addend = a.addend != nullptr;
-        if constexpr (BATCH) {
-            if (late_addend) {
+        if constexpr (LB == 1) {
+            // One-digit operands.  A wave issues at most one instruction every 4 clocks, scalar ones
+            // included, so the epilogue is priced in INSTRUCTIONS per element (the int64 form: 44, of
+            // them 9 64-bit multiply-adds).  Here: fp64 arithmetic (qf_epi_f64, 15 instructions), and
+            // output / addend addressed through buffer descriptors -- base = the block's first message
+            // row at the row block's first column, records = the bytes of the messages that exist, so
+            // the hardware range check IS the batch bound (loads beyond it return 0, stores are
+            // dropped) and an element's address is one v_add of a scalar row offset to the lane's
+            // offset (message 4h, column lane & 31).  No per-element branch, no 64-bit address math.
+            constexpr bool BATCH = !PACKED;
+            const uint64_t mu0 = (mb0 + i) * 32, col0 = (uint64_t)(rb0 + j) * 32;
+            const int64_t mleft = (int64_t)a.B - (int64_t)mu0;
+            if (mleft <= 0) continue;
+            const uint32_t mlim = mleft > 32 ? 32u : (uint32_t)mleft;            // messages of this block inside the batch
+            const uint32_t nrec = mlim * rowbytes - (uint32_t)col0 * 4;
+            const auto rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + mu0 * a.rows + col0), 0, (int)nrec, 0x00020000);
+            const auto rs_add = __builtin_amdgcn_make_buffer_rsrc((void *)(a.addend + mu0 * a.rows + col0), 0, a.addend ? (int)nrec : 0, 0x00020000);
+            const bool has_last = a.msg != nullptr && lastrow - (rb0 + j) * 32 < 32;
+            uint32_t add[BATCH ? 16 : 1];
+            if constexpr (BATCH) {
+                if (a.addend) {          // 16 loads in flight
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    uint64_t mrow = (mb0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    mrow = mrow < a.B ? mrow : a.B - 1;
-                    add[r] = a.addend[mrow * a.rows + krow];
+                    for (int r = 0; r < 16; r++)
+                        add[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_add, (int)(voff_st + ((r & 3) + 8 * (r >> 2)) * rowbytes), 0, 0);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) add[r] = 0;
                 }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; r++) add[r] = 0;
             }
+#ifdef QF_STAMP
+            QF_T(te0)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            QF_T(te1)
+            QF_ACC(s_eld, te0, te1)
+#endif
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int fr = (r & 3) + 8 * (r >> 2);
+                const int voff = (int)(voff_st + fr * rowbytes);
+#ifdef QF_ABL_NOEPI
+                if (acc[i][j][0][r] == 0x7fffffff) __builtin_amdgcn_raw_buffer_store_b32(acc[i][j][S > 1 ? 1 : 0][r] + acc[i][j][S - 1][r], rs_out, voff, 0, 0);
+                continue;
+#endif
+                double extra;
+                if constexpr (BATCH) extra = (double)add[r];
+                else extra = (double)(uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_add, voff, 0, 0);
+                if (has_last) {   // uniform: only the row block that holds the last key row
+                    asm volatile("");
+                    if (krow == lastrow && ((msgmask[i] >> (fr + 4 * he)) & 1)) extra += (double)a.mod.qhalf;
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(
+                    (int)qf_epi_f64<S>(acc[i][j][0][r], acc[i][j][S > 1 ? 1 : 0][r], acc[i][j][S > 2 ? 2 : 0][r], acc[i][j][S > 3 ? 3 : 0][r], extra, a),
+                    rs_out, voff, 0, 0);
+            }
+#ifdef QF_STAMP
+            QF_T(te2)
+            QF_ACC(s_ecomp, te1, te2)
+#endif
+        } else {
+        uint32_t add[16];
+        const bool late_addend = a.addend != nullptr;
+        if (late_addend) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                uint64_t mrow = (mb0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                mrow = mrow < a.B ? mrow : a.B - 1;
+                add[r] = a.addend[mrow * a.rows + krow];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) add[r] = 0;
         }
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const uint64_t mrow = (mb0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (mrow >= a.B) continue;
-#ifdef QF_ABL_NOEPI
-            if (acc[i][j][0][r] == 0x7fffffff) a.out[mrow] = acc[i][j][1][r] + acc[i][j][S - 1][r];
-            continue;
-#endif
             int64_t x = 0;
 #pragma unroll
             for (int s = 0; s < S; s++) x += (int64_t)acc[i][j][s][r] * (int64_t)a.cs[s];
-            if constexpr (BATCH) x += (int64_t)add[r];
-            else if (late_addend) x += (int64_t)a.addend[mrow * a.rows + krow];
+            x += (int64_t)add[r];
             if (krow == lastrow && ((msgmask[i] >> ((r & 3) + 8 * (r >> 2) + 4 * h)) & 1)) x += (int64_t)a.mod.qhalf;
             a.out[mrow * a.rows + krow] = qf_red_i64(x, a.mod);
+        }
         }
     }
     }
 #ifdef QF_STAMP
+    QF_T(te3)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     QF_T(tl2)
+    QF_ACC(s_edrain, te3, tl2)
     QF_ACC(s_epi, tl1, tl2)
     if (a.dbg && lane == 0) {
         unsigned long long *d = a.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * QF_NW + wave) * 8;
         d[0] = s_loop; d[1] = s_vm; d[2] = s_bar; d[3] = s_at; d[4] = s_epi; d[5] = tl0; d[6] = tl2;
+        unsigned long long *d2 = a.dbg + (size_t)gridDim.x * gridDim.y * QF_NW * 8 + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * QF_NW + wave) * 4;
+        d2[0] = s_eld; d2[1] = s_ecomp; d2[2] = s_edrain; d2[3] = tl1;
     }
 #endif
 }
@@ -885,6 +945,11 @@ __device__ __forceinline__ void qf_gemm_body16(const QfGemmArgs &a, const uint32
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
     const int lane = (int)lane_e, lc = lane & 15, lq = lane >> 4;
     const uint32_t lastrow = a.rows - 1;
+    const uint32_t rowbytes = a.rows * 4;
+    const uint32_t voff = (uint32_t)(4 * lq) * rowbytes + (uint32_t)lc * 4;
+    const int64_t mleft = (int64_t)a.B - (int64_t)(mb0 * 32);
+    if (mleft <= 0) return;                                       // uniform; nothing after the epilogue
+    const uint32_t mlim = mleft > 32 ? 32u : (uint32_t)mleft;     // messages of this wave's block inside the batch
 #pragma unroll
     for (int mg = 0; mg < 2; mg++) {
 #pragma unroll
@@ -918,20 +983,32 @@ __device__ __forceinline__ void qf_gemm_body16(const QfGemmArgs &a, const uint32
             }
             continue;
         }
+        // plain blocks: fp64 arithmetic, buffer descriptors whose record count is the batch bound (see
+        // qf_gemm_body's epilogue); lane offset = (message 4*lq, column lc), element = + (16*mg + r) rows,
+        // + 64 bytes for the second row half
+        if (rb0 + j >= a.rb) continue;
+        const uint64_t col0 = (uint64_t)(rb0 + j) * 32;
+        const uint32_t nrec = mlim * rowbytes - (uint32_t)col0 * 4;
+        const auto rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + mb0 * 32 * a.rows + col0), 0, (int)nrec, 0x00020000);
+        const auto rs_add = __builtin_amdgcn_make_buffer_rsrc((void *)(a.addend + mb0 * 32 * a.rows + col0), 0, a.addend ? (int)nrec : 0, 0x00020000);
+        const bool has_last = a.msg != nullptr && lastrow - (rb0 + j) * 32 < 32;
 #pragma unroll
         for (int kg = 0; kg < 2; kg++) {
             const uint32_t krow = (rb0 + j) * 32 + 16 * kg + lc;
-            if (rb0 + j >= a.rb || krow >= a.rows) continue;
+            if (krow >= a.rows) continue;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const uint64_t mrow = mb0 * 32 + 16 * mg + 4 * lq + r;
-                if (mrow >= a.B) continue;
-                int64_t x = 0;
-#pragma unroll
-                for (int s = 0; s < S; s++) x += (int64_t)acc[mg][j][kg][s][r] * (int64_t)a.cs[s];
-                if (a.addend) x += (int64_t)a.addend[mrow * a.rows + krow];
-                if (krow == lastrow && ((msgmask >> (16 * mg + 4 * lq + r)) & 1)) x += (int64_t)a.mod.qhalf;
-                a.out[mrow * a.rows + krow] = qf_red_i64(x, a.mod);
+                const int vo = (int)(voff + (16 * mg + r) * rowbytes) + 64 * kg;
+                double extra = 0.0;
+                if (a.addend) extra = (double)(uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_add, vo, 0, 0);
+                if (has_last) {   // uniform: only the row block that holds the last key row
+                    asm volatile("");
+                    if (krow == lastrow && ((msgmask >> (16 * mg + 4 * lq + r)) & 1)) extra += (double)a.mod.qhalf;
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(
+                    (int)qf_epi_f64<S>(acc[mg][j][kg][0][r], acc[mg][j][kg][S > 1 ? 1 : 0][r], acc[mg][j][kg][S > 2 ? 2 : 0][r],
+                                       acc[mg][j][kg][S > 3 ? 3 : 0][r], extra, a),
+                    rs_out, vo, 0, 0);
             }
         }
     }
@@ -1185,20 +1262,22 @@ int qf_launch_gemm(qf_ctx *ctx, const qf_key *key, const void *X, int x_is_bits,
     }
     const int la = key->la;
     a.xlb_total = (uint32_t)lb; a.xlb_off = 0;
+    if (key->rows >= (1u << 24)) return qf_fail(ctx, QF_ERR_NOTSUP, "gemm: more than 2^24 key rows (36 output rows are addressed through a 32-bit offset)");
+    // fp64 epilogue of the one-digit kernels (qf_epi_f64): |acc| <= K * (bits: 2^7, digits: 2^14), K counted
+    // with the folded digits; recombination in one step while 257 * 65536 * |acc| + 2^34 < 2^52
+    a.qd = (double)key->q; a.qinv = 1.0 / (double)key->q;
+    {
+        long double accmax = (long double)key->ks * 32.0L * (x_is_bits ? 128.0L : 16384.0L * lb);
+        a.epi2 = accmax * 257.0L * 65536.0L + 17179869184.0L >= 4503599627370496.0L ? 1u : 0u;
+        if (const char *e = getenv("QF_GEMM_EPI2")) a.epi2 = atoi(e) != 0;   // tests: force the two-step recombination
+    }
     if (x_is_bits && lb != 1) return qf_fail(ctx, QF_ERR_ARG, "gemm: bit operand has one digit");
-    // Wide batch operands (LB digits) on a long inner dimension: one pass PER DIGIT of the operand
-    // with the single-digit kernel -- pass b multiplies by 2^(8b) through shifted recombination
-    // constants and adds the previous passes' output as its addend.  Same MFMA count as the fused
-    // <LA,LB> kernel, but S = LA accumulators per row block instead of LA+LB-1 and 4 instead of
-    // 4*LB operand fragments in registers, so the wider tile and the register-prefetch pipeline
-    // fit: +10 % on SIS with Z_q inputs (K = 11,776).  Each pass re-reads and re-writes the output,
-    // so short inner dimensions (LPR, K = 1,024: 0.90 -> 1.29 ms) stay on the fused kernel.
-    // QF_GEMM_MULTIPASS=0/1 forces either.
     // Operand digits folded into the inner dimension (default): A*x = [A | 256A | ...]*[x_0; x_1; ...]
     // over LB*K columns with the single-digit kernel.  Same MFMA count as the fused <LA,LB> kernel,
     // S = LA accumulators per row block, ONE pass (no output re-read), the batch planes are consumed
     // exactly as the recode kernel lays them out ([mb][ks][lb] = k-step ks*LB + b).  Needs
-    // LB*K*2^14 < 2^31 for the int32 accumulators.  QF_GEMM_FOLD=0 disables it.
+    // LB*K*2^14 < 2^31 for the int32 accumulators -- which the check above already demands of every
+    // product with LB <= LA, so the fused <LA,LB> kernels below only run under QF_GEMM_FOLD=0 (tests).
     bool fold = !x_is_bits && lb > 1 && (long double)lb * key->ks * 32.0L * 16384.0L < 2147483648.0L;
     if (const char *e = getenv("QF_GEMM_FOLD")) fold = fold && atoi(e) != 0;
     if (fold) {
@@ -1215,29 +1294,6 @@ int qf_launch_gemm(qf_ctx *ctx, const qf_key *key, const void *X, int x_is_bits,
             case 4: return qf_gemm_dispatch<4, 1, false>(ctx, p);
         }
         return qf_fail(ctx, QF_ERR_NOTSUP, "gemm: digit count not instantiated");
-    }
-    bool multipass = (uint64_t)key->ks * 32 >= 4096;
-    if (const char *e = getenv("QF_GEMM_MULTIPASS")) multipass = atoi(e) != 0;
-    if (!x_is_bits && lb > 1 && multipass) {
-        QfGemmArgs p = a;
-        float ms_total = 0.f;
-        for (int b = 0; b < lb; b++) {
-            p.xlb_off = (uint32_t)b;
-            for (int s = 0; s < 8; s++) p.cs[s] = s + b < 8 ? a.cs[s + b] : 0;
-            p.addend = b == 0 ? addend : out;   // in place: every thread reads the element it then writes
-            p.msg = b == 0 ? msg : nullptr;
-            int rc = QF_ERR_NOTSUP;
-            switch (la) {
-                case 1: rc = qf_gemm_dispatch<1, 1, false>(ctx, p); break;
-                case 2: rc = qf_gemm_dispatch<2, 1, false>(ctx, p); break;
-                case 3: rc = qf_gemm_dispatch<3, 1, false>(ctx, p); break;
-                case 4: rc = qf_gemm_dispatch<4, 1, false>(ctx, p); break;
-            }
-            if (rc) return rc;
-            ms_total += ctx->ms_gemm;
-        }
-        if (ctx->timing) ctx->ms_gemm = ms_total;   // "gemm" time of the call = all passes
-        return QF_OK;
     }
 #define QF_CASE(LA_, LB_)                                                            \
     if (la == LA_ && lb == LB_) {                                                    \

@@ -321,7 +321,7 @@ def test_dot_decode_ragged_and_large_n(ctx):
         assert np.array_equal(bits, co.dot_decode_batch(s, q, Cm)), (n, q, B)
 
 
-@pytest.mark.parametrize("env", [{}, {"QF_GEMM_FOLD": "0"}, {"QF_GEMM_FOLD": "0", "QF_GEMM_MULTIPASS": "0"}])
+@pytest.mark.parametrize("env", [{}, {"QF_GEMM_FOLD": "0"}, {"QF_GEMM_EPI2": "1"}])
 def test_matmul_wide_operand_paths(ctx, monkeypatch, env):
     """Wide operands, the three ways qf_launch_gemm can run them -- digits folded into the inner
     dimension (default), one pass per digit (K >= 4096), the fused <LA,LB> kernel: same bits as

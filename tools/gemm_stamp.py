@@ -22,14 +22,18 @@ else:
     xb = ctx.sample_bits(1, 3, 0, B, m)
     nwaves = (B // 256) * 3 * 8
     run = lambda: ctx.matmul(key, xb, X_BITS, B)
-dbg = torch.zeros(nwaves * 8, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(nwaves * 12, dtype=torch.int64, device="cuda")
 ctx.lib.qf_debug_set_buffer(ctypes.c_void_p(dbg.data_ptr()))
 for _ in range(3):
     run()
 torch.cuda.synchronize()
-d = dbg.cpu().numpy().reshape(nwaves, 8)
+raw = dbg.cpu().numpy()
+d = raw[:nwaves * 8].reshape(nwaves, 8)
+d2 = raw[nwaves * 8:].reshape(nwaves, 4)
 tot = (d[:, 6] - d[:, 5]).mean()
 print("per-wave cycles: total %.0f loop %.0f vmcnt-wait %.0f barrier %.0f at-wait %.0f epilogue %.0f" %
       (tot, d[:, 0].mean(), d[:, 1].mean(), d[:, 2].mean(), d[:, 3].mean(), d[:, 4].mean()))
 print("shares of total: loop %.3f vm %.3f bar %.3f at %.3f epi %.3f" % tuple(d[:, i].mean() / tot for i in range(5)))
 print("kernel span cycles (max end - min start): %d" % (d[:, 6].max() - d[:, 5].min()))
+print("epilogue split: addend-load wait %.0f  compute+store issue %.0f  final store drain %.0f (cycles per wave, 100 MHz s_memtime ticks x clock ratio)" %
+      (d2[:, 0].mean(), d2[:, 1].mean(), d2[:, 2].mean()))

@@ -22,6 +22,9 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed) {
                        uint64_t t = (uint64_t)f * h + e; f = (uint32_t)t | 1; h = (uint32_t)(t >> 32) | 1; }
         if (OP == 4) { x = fma(x, y, z); w = fma(w, y, z); z = fma(z, y, x); y = fma(y, 0.999, 1e-9); 
                        x = fma(x, y, w); w = fma(w, y, x); z = fma(z, 0.5, x); y = fma(y, 1.0, 1e-12);}
+        if (OP == 6) { x = (double)(int)a + x; a = (uint32_t)(int)w; w = (double)(int)c + w; c = (uint32_t)(int)x;
+                       z = (double)(int)e + z; e = (uint32_t)(int)y; y = (double)(int)g + z; g = (uint32_t)(int)z; }   // 4 cvt_f64_i32 + 4 cvt_i32_f64 + 4 add_f64
+        if (OP == 7) { x = __builtin_rint(x * y) + z; w = __builtin_rint(w * y) + x; z = __builtin_rint(z * 0.37) + w; y = __builtin_rint(y * 1.7) + 0.3; }  // 4 mul + 4 rndne + 4 add
         if (OP == 5) { a = __mul24(a, b) + c; c = __mul24(c, d) + a; e = __mul24(e, f) + g; g = __mul24(g, h) + e;
                        b = __mul24(b, a) + d; d = __mul24(d, c) + b; f = __mul24(f, e) + h; h = __mul24(h, g) + f; }
     }
@@ -50,17 +53,19 @@ static float timeit(F f) {
 int main() {
     uint32_t *out; hipMalloc(&out, 256 * 2048 * 4 * 4);
     const int blocks = 256 * 8;  // 8 waves per SIMD
-    const char *names[] = {"v_add_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u64_u32", "v_fma_f64", "v_mad_u32_u24"};
+    const char *names[] = {"v_add_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u64_u32", "v_fma_f64", "v_mad_u32_u24", "cvt f64<->i32 + add_f64 (12 ops)", "mul/rndne/add f64 (12 ops)"};
     double ops = (double)blocks * 256 * N_ITER * 8;
-    float ms[6];
+    float ms[8];
     ms[0] = timeit([&] { hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 0, 0, out, 1u); });
     ms[1] = timeit([&] { hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, out, 1u); });
     ms[2] = timeit([&] { hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 0, 0, out, 1u); });
     ms[3] = timeit([&] { hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(256), 0, 0, out, 1u); });
     ms[4] = timeit([&] { hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(256), 0, 0, out, 1u); });
     ms[5] = timeit([&] { hipLaunchKernelGGL(k<5>, dim3(blocks), dim3(256), 0, 0, out, 1u); });
-    for (int i = 0; i < 6; i++) {
-        double per = (i == 3) ? ops / 2 : ops;  // OP 3 issues 4 mads per iteration (others 8 ops)
+    ms[6] = timeit([&] { hipLaunchKernelGGL(k<6>, dim3(blocks), dim3(256), 0, 0, out, 1u); });
+    ms[7] = timeit([&] { hipLaunchKernelGGL(k<7>, dim3(blocks), dim3(256), 0, 0, out, 1u); });
+    for (int i = 0; i < 8; i++) {
+        double per = (i == 3) ? ops / 2 : (i >= 6 ? ops * 1.5 : ops);  // OP 3 issues 4 mads per iteration (others 8 ops)
         printf("%-16s %8.3f ms  %.2f Tlane-op/s\n", names[i], ms[i], per / ms[i] * 1e-9);
     }
     float m = timeit([&] { hipLaunchKernelGGL(kmfma, dim3(256 * 2), dim3(256), 0, 0, (int *)out, 1); });
