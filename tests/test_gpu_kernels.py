@@ -2,6 +2,7 @@
 (oracle/qf_oracle.c) on the same seeded inputs.  Bit-exact -- this is integer work."""
 import numpy as np
 import pytest
+import torch
 
 from oracle import coracle as co
 from crypto_amd.device import X_BITS, X_I32, X_U32, bit_stride, pack_bits
@@ -516,3 +517,51 @@ def test_matmul_bits_with_addend_on_packed_remainder(ctx, rows, cols, q, B):
     assert np.array_equal(ctx.to_host_u32(out), co.matmul_batch(A, q, xb, co.X_BITS, B, addend=E, msg=msg))
     out = ctx.matmul(key, ctx.to_dev_u8(xb), X_BITS, B, addend=ctx.to_dev_u32(E))
     assert np.array_equal(ctx.to_host_u32(out), co.matmul_batch(A, q, xb, co.X_BITS, B, addend=E))
+
+
+@pytest.mark.parametrize("rows,cols,q,B", [(40, 100, 2147483647, 45), (33, 260, 2147483629, 33), (70, 64, 3, 65), (5, 40, 2, 31),
+                                           (96, 128, 2147483647, 64), (64, 96, 1073741827, 32)])
+def test_matmul_epilogue_extreme_moduli(ctx, rows, cols, q, B):
+    """The fp64 epilogue of the one-digit kernels (qf_gemm.h qf_epi_f64) at the ends of the modulus range: the largest
+    moduli the library takes (2^31 - 1 and the prime below it), q just above 2^30, q = 2 and 3; bit operands with message,
+    digit operands with addend and message."""
+    A = co.sample_uniform(SEED, 1, 0, rows * cols, q).reshape(rows, cols)
+    key = ctx.key_upload(A, q)
+    msg = (co.sample_uniform(SEED, 5, 0, B, 2)).astype(np.uint8)
+    xb = co.sample_bits(SEED, 3, 0, B, cols, bit_stride(cols))
+    out = ctx.matmul(key, ctx.to_dev_u8(xb), X_BITS, B, msg=ctx.to_dev_u8(msg))
+    assert np.array_equal(ctx.to_host_u32(out), co.matmul_batch(A, q, xb, co.X_BITS, B, msg=msg))
+    v = co.sample_uniform(SEED, 6, 0, B * cols, q).reshape(B, cols)
+    e = co.sample_uniform(SEED, 4, 0, B * rows, q).reshape(B, rows)
+    out = ctx.matmul(key, ctx.to_dev_u32(v), X_U32, B, addend=ctx.to_dev_u32(e), msg=ctx.to_dev_u8(msg))
+    assert np.array_equal(ctx.to_host_u32(out), co.matmul_batch(A, q, v, co.X_U32, B, addend=e, msg=msg))
+
+
+def test_matmul_epilogue_two_step_recombination(ctx):
+    """A 4-digit key times a 4-digit operand over 8,200 columns: 257 * 65536 * |acc| passes 2^52, so the launcher
+    sets QfGemmArgs::epi2 and the upper digit pair is reduced before the recombination (no override here)."""
+    rows, cols, q, B = 34, 8200, 2147483647, 20
+    A = co.sample_uniform(SEED, 1, 0, rows * cols, q).reshape(rows, cols)
+    key = ctx.key_upload(A, q)
+    v = co.sample_uniform(SEED, 6, 0, B * cols, q).reshape(B, cols)
+    e = co.sample_uniform(SEED, 4, 0, B * rows, q).reshape(B, rows)
+    out = ctx.matmul(key, ctx.to_dev_u32(v), X_U32, B, addend=ctx.to_dev_u32(e))
+    assert np.array_equal(ctx.to_host_u32(out), co.matmul_batch(A, q, v, co.X_U32, B, addend=e))
+
+
+@pytest.mark.parametrize("B", [1, 31, 33, 257])
+def test_matmul_never_writes_beyond_the_batch(ctx, B):
+    """The epilogue's stores go through a buffer descriptor whose record count is the batch bound: rows of the last,
+    partial message block beyond B must stay untouched (guard rows behind the output), with bit and digit operands."""
+    rows, cols, q = 45, 200, 8380417
+    A = co.sample_uniform(SEED, 1, 0, rows * cols, q).reshape(rows, cols)
+    key = ctx.key_upload(A, q)
+    e = co.sample_uniform(SEED, 4, 0, B * rows, q).reshape(B, rows)
+    xb = co.sample_bits(SEED, 3, 0, B, cols, bit_stride(cols))
+    v = co.sample_uniform(SEED, 6, 0, B * cols, q).reshape(B, cols)
+    for X, kind, ckind, xh in ((ctx.to_dev_u8(xb), X_BITS, co.X_BITS, xb), (ctx.to_dev_u32(v), X_U32, co.X_U32, v)):
+        big = torch.full((B + 40, rows), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+        ctx.matmul(key, X, kind, B, addend=ctx.to_dev_u32(e), out=big[:B])
+        host = ctx.to_host_u32(big)
+        assert np.array_equal(host[:B], co.matmul_batch(A, q, xh, ckind, B, addend=e))
+        assert (host[B:] == 0x5A5A5A5A).all()

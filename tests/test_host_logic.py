@@ -171,3 +171,11 @@ def test_asm_window_checker_flags_a_touched_destination(tmp_path):
     assert subprocess.run([sys.executable, tool, str(good), "qf_gemm"], capture_output=True).returncode == 0
     r = subprocess.run([sys.executable, tool, str(bad), "qf_gemm"], capture_output=True, text=True)
     assert r.returncode != 0 and "v[12]" in r.stdout
+    # the state follows branches, not file order: a path that jumps over the wait reaches the use with the LDS
+    # read still in flight
+    cfg = ("_Z7qf_gemmv: ; @_Z7qf_gemmv\n\t;;#ASMSTART\n\tds_read_b128 v[20:23], v1\n\t;;#ASMEND\n\ts_cbranch_scc1 .LBB0_2\n"
+           "; %%bb.1:\n\t;;#ASMSTART\n\ts_waitcnt lgkmcnt(0)\n\t;;#ASMEND\n%s.LBB0_2:\n\tv_mov_b32_e32 v6, v21\n\ts_endpgm\n.Lfunc_end0:\n")
+    bad2 = tmp_path / "bad2.s"
+    bad2.write_text(cfg % "")
+    r = subprocess.run([sys.executable, tool, str(bad2), "qf_gemm"], capture_output=True, text=True)
+    assert r.returncode != 0 and "v[21]" in r.stdout
