@@ -42,7 +42,7 @@ __device__ __forceinline__ v4i qf_expand16(uint32_t w16) {
 //   x = a0 + 256 a1 + 65536 (a2 + 256 a3) + extra     exact in a double: the host guarantees
 //       |x| < 2^52, or sets epi2 and the upper pair is reduced mod q first (|65536 hi'| < 2^47);
 //   t = rint(x / q), r = x - t q                        one fma, exact: an integer, |r| <= q/2 + 1/4;
-//   result = r < 0 ? r + q : r                          in 32-bit integers.
+//   result = min(r, r + q) as unsigned words            (r < 0 wraps to >= 2^31 > r + q; q < 2^31).
 // Signed digits represent an entry EXACTLY (sum d_s 256^s = its representative), so the true powers
 // of 256 are used here, not the centred residues cs[].
 template <int S>
@@ -60,6 +60,7 @@ __device__ __forceinline__ uint32_t qf_epi_f64(int a0, int a1, int a2, int a3, d
         x = __builtin_fma(hi, 65536.0, x);
     }
     const double t = __builtin_rint(x * a.qinv);
-    const int r = (int)__builtin_fma(-t, a.qd, x);
-    return (uint32_t)r + ((uint32_t)(r >> 31) & a.mod.q);
+    const uint32_t r = (uint32_t)(int)__builtin_fma(-t, a.qd, x);
+    const uint32_t rq = r + a.mod.q;
+    return r < rq ? r : rq;
 }

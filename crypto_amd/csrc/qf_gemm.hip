@@ -692,6 +692,12 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a, const uint32_t
             QF_T(te1)
             QF_ACC(s_eld, te0, te1)
 #endif
+            if constexpr (BATCH)
+                if (has_last) {   // the one row block with the last key row: message term folded into the addend words (< 2^32)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        add[r] += (krow == lastrow && ((msgmask[i] >> ((r & 3) + 8 * (r >> 2) + 4 * he)) & 1)) ? a.mod.qhalf : 0u;
+                }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int fr = (r & 3) + 8 * (r >> 2);
@@ -703,10 +709,11 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a, const uint32_t
                 double extra;
                 if constexpr (BATCH) extra = (double)add[r];
                 else extra = (double)(uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_add, voff, 0, 0);
-                if (has_last) {   // uniform: only the row block that holds the last key row
-                    asm volatile("");
-                    if (krow == lastrow && ((msgmask[i] >> (fr + 4 * he)) & 1)) extra += (double)a.mod.qhalf;
-                }
+                if constexpr (!BATCH)
+                    if (has_last) {   // uniform: only the row block that holds the last key row
+                        asm volatile("");
+                        if (krow == lastrow && ((msgmask[i] >> (fr + 4 * he)) & 1)) extra += (double)a.mod.qhalf;
+                    }
                 __builtin_amdgcn_raw_buffer_store_b32(
                     (int)qf_epi_f64<S>(acc[i][j][0][r], acc[i][j][S > 1 ? 1 : 0][r], acc[i][j][S > 2 ? 2 : 0][r], acc[i][j][S > 3 ? 3 : 0][r], extra, a),
                     rs_out, voff, 0, 0);
