@@ -324,9 +324,9 @@ def test_dot_decode_ragged_and_large_n(ctx):
 
 @pytest.mark.parametrize("env", [{}, {"QF_GEMM_FOLD": "0"}, {"QF_GEMM_EPI2": "1"}])
 def test_matmul_wide_operand_paths(ctx, monkeypatch, env):
-    """Wide operands, the three ways qf_launch_gemm can run them -- digits folded into the inner
-    dimension (default), one pass per digit (K >= 4096), the fused <LA,LB> kernel: same bits as
-    the oracle, with addend and message, for 2- and 3-digit operands."""
+    """Wide operands, the ways qf_launch_gemm can run them -- digits folded into the inner dimension
+    (default), the fused <LA,LB> kernel, the fold with the two-step fp64 recombination forced: same
+    bits as the oracle, with addend and message, for 2- and 3-digit operands."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     n, m, q, B = 40, 4500, 8380417, 50
