@@ -93,7 +93,12 @@ int qf_ctx_create(int device, void *stream, qf_ctx **out) {
     ctx->stream = (hipStream_t)stream;
     if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&ctx->flag, 256) != hipSuccess ||
         hipMemset(ctx->flag, 0, 256) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
-        hipEventCreate(&ctx->ev1) != hipSuccess) {
+        hipEventCreate(&ctx->ev1) != hipSuccess || hipEventCreateWithFlags(&ctx->evf, hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc((void **)&ctx->hflag, 64, hipHostMallocDefault) != hipSuccess) {
+        if (ctx->flag) hipFree(ctx->flag);
+        if (ctx->ev0) hipEventDestroy(ctx->ev0);
+        if (ctx->ev1) hipEventDestroy(ctx->ev1);
+        if (ctx->evf) hipEventDestroy(ctx->evf);
         delete ctx;
         return QF_ERR_DEVICE;
     }
@@ -119,6 +124,8 @@ void qf_ctx_destroy(qf_ctx *ctx) {
     if (ctx->cdt) hipFree(ctx->cdt);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->evf) hipEventDestroy(ctx->evf);
+    if (ctx->hflag) hipHostFree(ctx->hflag);
     delete ctx;
 }
 int qf_sync(qf_ctx *ctx) {
@@ -345,28 +352,43 @@ int qf_matmul_modq_dev(qf_ctx *ctx, const qf_key *key, const void *X_dev, int x_
     }
     if (x_kind != QF_X_U32 && x_kind != QF_X_I32) return qf_fail(ctx, QF_ERR_ARG, "matmul: unknown operand kind");
     if (x_stride_bytes < (size_t)key->cols * 4 || x_stride_bytes % 4) return qf_fail(ctx, QF_ERR_DIM, "matmul: operand rows shorter than the key's column count");
+    if (B > 0xFFFFFFFFull) return qf_fail(ctx, QF_ERR_NOTSUP, "matmul: batch too large");
     int lb = (x_digits >= 1 && x_digits < key->la) ? x_digits : key->la;
+    // A digit promise (lb < la) is verified by the recode kernel; the product is launched right behind it
+    // WITHOUT waiting for the verdict -- the host reads the flag (copied to pinned memory behind the recode)
+    // while the GEMM runs, and only a broken promise costs anything: the product is redone at full width
+    // over the same output (exact for every input).
     for (;;) {
+        const bool promised = lb < key->la;
         size_t pbytes = (size_t)((B + 31) / 32) * key->ks * lb * 1024;
         int rc = qf_ws_reserve(ctx, pbytes);
         if (rc) return rc;
         rc = qf_launch_recode(ctx, X_dev, x_kind, x_stride_bytes, (uint32_t)B, key->cols, key->mod, lb, key->ks,
                               (int8_t *)ctx->ws, ctx->flag);
         if (rc) return rc;
-        if (lb < key->la) {  // a promise was made: verify it before trusting the planes
-            uint32_t flag = 0;
-            QF_HIP(ctx, hipMemcpyAsync(&flag, ctx->flag, 4, hipMemcpyDeviceToHost, ctx->stream));
-            QF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (flag) {
-                QF_HIP(ctx, hipMemsetAsync(ctx->flag, 0, 4, ctx->stream));
-                lb = key->la;  // promise broken: redo at full width (exact for every input)
-                continue;
-            }
+        if (promised) {
+            QF_HIP(ctx, hipMemcpyAsync(ctx->hflag, ctx->flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+            QF_HIP(ctx, hipEventRecord(ctx->evf, ctx->stream));
         }
-        break;
+        // in-place accumulation (addend == out): a product over unverified planes would destroy the addend
+        const bool in_place = promised && (const void *)addend_dev == (const void *)out_dev;
+        bool broken = false;
+        if (in_place) {
+            QF_HIP(ctx, hipEventSynchronize(ctx->evf));
+            broken = *(volatile uint32_t *)ctx->hflag != 0;
+        }
+        if (!broken) {
+            rc = qf_launch_gemm(ctx, key, ctx->ws, 0, 0, lb, B, addend_dev, msg_dev, out_dev);
+            if (rc || !promised) return rc;
+            if (!in_place) {
+                QF_HIP(ctx, hipEventSynchronize(ctx->evf));
+                broken = *(volatile uint32_t *)ctx->hflag != 0;
+            }
+            if (!broken) return QF_OK;
+        }
+        QF_HIP(ctx, hipMemsetAsync(ctx->flag, 0, 4, ctx->stream));
+        lb = key->la;  // promise broken: redo at full width
     }
-    if (B > 0xFFFFFFFFull) return qf_fail(ctx, QF_ERR_NOTSUP, "matmul: batch too large");
-    return qf_launch_gemm(ctx, key, ctx->ws, 0, 0, lb, B, addend_dev, msg_dev, out_dev);
 }
 
 // ------------------------------------------------------------------ kernel (c)

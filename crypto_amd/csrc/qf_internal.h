@@ -20,6 +20,8 @@ struct qf_ctx {
     uint32_t *hostvec = nullptr;  // staging of the *_host single-message entry points (x then y)
     size_t hostvec_words = 0;
     uint32_t *flag = nullptr; // device error flag (range violations)
+    uint32_t *hflag = nullptr; // pinned host copy of it + the event behind the copy (digit-promise check of qf_matmul_modq_dev)
+    hipEvent_t evf = nullptr;
     // discrete-Gaussian inversion table of the last (n, s) asked for (qf_sample_discrete_gauss_dev)
     uint64_t *cdt = nullptr;
     uint32_t cdt_len = 0, cdt_n = 0;

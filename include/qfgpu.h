@@ -111,7 +111,11 @@ int qf_key_replicate(qf_ctx *const *ctxs, int n, const qf_key *src_key, qf_key *
  * x_stride_bytes: distance between consecutive rows of X.  x_digits: 0 = full width, or a
  * promise that every centred entry of X fits in that many signed 8-bit digits (1..4); a broken
  * promise is detected on the device and the product is redone at full width (never wrong).
- * addend_dev / msg_dev may be NULL. */
+ * addend_dev / msg_dev may be NULL; addend_dev may BE out_dev (in-place accumulation), any other overlap
+ * of the two is undefined.  The call returns with the product queued on the stream; with a digit promise
+ * it has waited for the recode pass (not for the product) to learn whether the promise held.  Limits (QF_ERR_NOTSUP beyond them): digits(X) * cols * 2^14 < 2^31
+ * (int32 accumulators; 43,690 columns for a 3-digit operand, 131,071 for bits or one digit), fewer than
+ * 2^24 key rows, B < 2^32.  out_dev needs exactly B * rows words: nothing beyond row B-1 is written. */
 int qf_matmul_modq_dev(qf_ctx *ctx, const qf_key *key, const void *X_dev, int x_kind,
                        size_t x_stride_bytes, int x_digits, uint64_t B,
                        const uint32_t *addend_dev, const uint8_t *msg_dev, uint32_t *out_dev);

@@ -565,3 +565,18 @@ def test_matmul_never_writes_beyond_the_batch(ctx, B):
         host = ctx.to_host_u32(big)
         assert np.array_equal(host[:B], co.matmul_batch(A, q, xh, ckind, B, addend=e))
         assert (host[B:] == 0x5A5A5A5A).all()
+
+
+@pytest.mark.parametrize("W,digits", [(100, 1), (30000, 1), (30000, 2)])
+def test_matmul_in_place_accumulation_with_digit_promise(ctx, W, digits):
+    """addend == out (include/qfgpu.h): the product over a promised digit count is launched before the promise is
+    known to hold, except in place, where a broken promise (W = 30000 does not fit one digit) would have destroyed
+    the addend before the full-width redo."""
+    n, q, B = 40, 65521, 70
+    pk = co.sample_uniform(SEED, 1, 0, (n + 1) * n, q).reshape(n + 1, n)
+    r = co.sample_noise(SEED, 3, 0, B * n, q, W).reshape(B, n)
+    e = co.sample_uniform(SEED, 4, 0, B * (n + 1), q).reshape(B, n + 1)
+    key = ctx.key_upload(pk, q)
+    buf = ctx.to_dev_u32(e)
+    ctx.matmul(key, ctx.to_dev_u32(r), X_U32, B, addend=buf, x_digits=digits, out=buf)
+    assert np.array_equal(ctx.to_host_u32(buf), co.matmul_batch(pk, q, r, co.X_U32, B, addend=e))
