@@ -3,9 +3,11 @@
 //   out[b][i] = sum_j key[i][j] * X[b][j]  (+ addend[b][i]) (+ msg[b]*floor(q/2) on the last row)  mod q
 //
 // Both operands are split into signed radix-2^8 digits (d in [-128,127]); the product of two
-// digit planes is an exact int8 x int8 -> int32 MFMA (v_mfma_i32_32x32x32_i8).  Digit pairs with
-// the same weight 2^(8s) share one int32 accumulator; the epilogue recombines the S = LA+LB-1
-// accumulators in int64 with centred constants c_s = 2^(8s) mod q and does one Barrett reduction.
+// digit planes is an exact int8 x int8 -> int32 MFMA (v_mfma_i32_16x16x64_i8 for bit operands,
+// v_mfma_i32_32x32x32_i8 for digit-plane operands).  Digit pairs with the same weight 2^(8s) share
+// one int32 accumulator; the epilogue recombines the S = LA+LB-1 accumulators and reduces mod q --
+// in fp64 for one-digit operands (every default path: qf_epi_f64 in qf_gemm.h), in int64 with
+// centred constants c_s = 2^(8s) mod q and one Barrett reduction for the fused <LA,LB> kernels.
 //
 // HBM layout ("fragment order"): a digit plane of an R x K matrix is stored as
 //   [R/32 row blocks][K/32 k-steps][L digits][64 lanes][16 bytes]
@@ -19,7 +21,10 @@
 //   BITS   : 16 bits of the message row are expanded to 16 int8 {0,1} in registers,
 //   PLANES : pre-recoded digit fragments are loaded with one coalesced 16-byte load per lane.
 // MFMA roles: A (rows of D) = messages, B (columns of D) = key rows, so a lane ends up owning
-// one key row and 16 messages, and every store instruction writes two 128-byte runs.
+// one key row and 16 messages, and every store instruction writes two 128-byte runs (32x32x32;
+// four 64-byte runs with 16x16x64).  The other way round (a lane owns one message and 4 consecutive
+// key rows, 16-byte stores) was measured: 12 % slower on LPR -- a store that touches 32 rows costs
+// the memory pipeline more than the instructions it saves (profiles/r2/gemm_ablation.log).
 #include <cstdlib>
 #include "qf_internal.h"
 
