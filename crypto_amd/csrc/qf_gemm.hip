@@ -842,9 +842,15 @@ __device__ __forceinline__ void qf_gemm_body16(const QfGemmArgs &a, const uint32
     asm volatile("" : "+v"(at[set_][1]));
     // 16 bits -> 16 bytes for k-step sp (of 64) of the tile whose words are in at[set_][mg_]: the lane's
     // bits are half (lq & 1) of dword 2*sp + (lq >> 1)
+    // the lane's 16 bits of the k-step: word (lq >> 1) of the step's two, half (lq & 1) of it.  The two
+    // candidate words pass through an empty asm: hipcc otherwise turns "cond ? v[3] : v[2]" into an
+    // element extract with a PER-LANE index and lowers that as a compare/select chain over all 16 dwords
+    // of at[][] (68 VALU instructions + hazard nops per k-tile instead of 4 selects).
 #define QF16_WSEL(set_, mg_, sp_) {                                                               \
-        const uint32_t w_ = (lq >> 1) ? (uint32_t)at[set_][mg_][2 * (sp_) + 1] : (uint32_t)at[set_][mg_][2 * (sp_)]; \
-        wsel[mg_] = (lq & 1) ? (w_ >> 16) : (w_ & 0xFFFFu); }
+        uint32_t w0_ = (uint32_t)at[set_][mg_][2 * (sp_)], w1_ = (uint32_t)at[set_][mg_][2 * (sp_) + 1]; \
+        asm volatile("" : "+v"(w0_), "+v"(w1_));                                                  \
+        const uint32_t w_ = hiword ? w1_ : w0_;                                                   \
+        wsel[mg_] = __builtin_amdgcn_ubfe(w_, halfsh, 16); }
 #define QF16_EXPAND(dst_, mg_, d_) dst_[d_] = (int)((((wsel[mg_] >> (4 * (d_))) & 0xFu) * 0x00204081u) & 0x01010101u);
 
     QF16_LOAD_AT(0, 0)
@@ -873,6 +879,8 @@ __device__ __forceinline__ void qf_gemm_body16(const QfGemmArgs &a, const uint32
     v4i ring[D];
     v4i afb[2][2];                    // [k-step of 64 (parity)][message half]
     uint32_t wsel[2];
+    const bool hiword = (lq >> 1) != 0;
+    const uint32_t halfsh = (uint32_t)(lq & 1) * 16;
 #pragma unroll
     for (int g = 0; g < D; g++) QF16_RD(g, laneA, laneP, g)
 #pragma unroll
