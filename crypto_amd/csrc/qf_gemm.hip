@@ -298,20 +298,37 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a, const uint32_t
     // Every wave issues exactly NSR DMA instructions per tile (a wave whose share runs past the
     // tile re-copies the last fragment: same bytes to the same place), so the stream has no
     // branches and hipcc can count vmcnt exactly around it.
+    // A piece's source is (tile-0 pointer of its fragment, loop-invariant, scalar) + tile * (bytes per
+    // k-tile of its row block) + lane * 16: two scalar adds per piece in the loop (hipcc re-derived the
+    // whole 64-bit product chain, 9 scalar instructions, for every piece of every tile).
 #define QF_STAGE(kt_, buf_) QF_STAGE_PART(kt_, buf_, 0, NSR)
-#define QF_STAGE_PART(kt_, buf_, i0_, i1_)                                                           \
-    _Pragma("unroll") for (int i_ = (i0_); i_ < (i1_); i_++) {                                       \
+#define QF_STAGE_SETUP()                                                                             \
+    const int8_t *stg_ptr[NSR];                                                                      \
+    uint32_t stg_stride[PACKED ? NSR : 1];                                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < NSR; i_++) {                                             \
         int f_ = wave + i_ * QF_NW;                                                                  \
         f_ = f_ < FRAGS ? f_ : FRAGS - 1;                                                            \
         const int j_ = f_ / (QF_KS * LA), rem_ = f_ % (QF_KS * LA);                                  \
         uint32_t rbi_ = rb0 + j_;                                                                    \
         rbi_ = rbi_ < a.rb ? rbi_ : a.rb - 1; /* padded column tile: harmless duplicate */           \
-        const int8_t *g_ = a.kplanes +                                                               \
-            ((((size_t)rbi_ * a.ks + (size_t)(kt_)*QF_KS) * LA + rem_) * 64 + lane) * 16;            \
-        if (PACKED && f_ >= (WN - 1) * QF_KS * LA)                                                   \
-            g_ = a.rem_planes + (((size_t)(kt_)*QF_KS + (f_ - (WN - 1) * QF_KS * LA)) * 64 + lane) * 16; \
+        stg_ptr[i_] = a.kplanes + ((size_t)rbi_ * a.ks * LA + rem_) * 1024;                          \
+        if constexpr (PACKED) {                                                                      \
+            stg_stride[i_] = QF_KS * LA * 1024;                                                      \
+            if (f_ >= (WN - 1) * QF_KS * LA) {                                                       \
+                stg_ptr[i_] = a.rem_planes + (size_t)(f_ - (WN - 1) * QF_KS * LA) * 1024;            \
+                stg_stride[i_] = QF_KS * 1024;                                                       \
+            }                                                                                        \
+        }                                                                                            \
+        asm volatile("" : "+s"(stg_ptr[i_]));                                                        \
+    }                                                                                                \
+    const uint32_t stg_lane16 = (uint32_t)lane * 16;
+#define QF_STAGE_PART(kt_, buf_, i0_, i1_)                                                           \
+    _Pragma("unroll") for (int i_ = (i0_); i_ < (i1_); i_++) {                                       \
+        const int8_t *t_ = stg_ptr[i_] + (size_t)(kt_) * (PACKED ? stg_stride[i_] : (uint32_t)(QF_KS * LA * 1024)); \
+        asm volatile("" : "+s"(t_));   /* scalar: keeps hipcc from hoisting NSR per-lane 64-bit addresses out of the loop */ \
+        const int8_t *g_ = t_ + stg_lane16;                                                          \
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g_,         \
-            (__attribute__((address_space(3))) void *)(smem + (buf_)*TILE_BYTES + f_ * 1024),        \
+            (__attribute__((address_space(3))) void *)(smem + (buf_)*TILE_BYTES + (wave + i_ * QF_NW < FRAGS ? wave + i_ * QF_NW : FRAGS - 1) * 1024), \
             16, 0, 0);                                                                               \
     }
 
@@ -407,6 +424,7 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a, const uint32_t
 #define QF_INTERLEAVE_V(NV_) QfSched<0, NBF, (NV_), MW * LB>::run(); __builtin_amdgcn_sched_barrier(0);
 
     QF_LOAD_AT(0, 0)
+    QF_STAGE_SETUP()
     QF_STAGE(0, 0)
     QF_STAGE(ntiles > 1 ? 1 : 0, 1)
     // message bits of this wave's MW*32 messages as one 32-bit mask per block (SGPRs), loaded here so
@@ -854,6 +872,7 @@ __device__ __forceinline__ void qf_gemm_body16(const QfGemmArgs &a, const uint32
 #define QF16_EXPAND(dst_, mg_, d_) dst_[d_] = (int)((((wsel[mg_] >> (4 * (d_))) & 0xFu) * 0x00204081u) & 0x01010101u);
 
     QF16_LOAD_AT(0, 0)
+    QF_STAGE_SETUP()
     QF_STAGE(0, 0)
     QF_STAGE(ntiles > 1 ? 1 : 0, 1)
     if (a.msg && (uint64_t)(rb0 + WN) * 32 >= a.rows) {
