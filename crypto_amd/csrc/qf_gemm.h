@@ -45,6 +45,23 @@ __device__ __forceinline__ v4i qf_expand16(uint32_t w16) {
 //   result = min(r, r + q) as unsigned words            (r < 0 wraps to >= 2^31 > r + q; q < 2^31).
 // Signed digits represent an entry EXACTLY (sum d_s 256^s = its representative), so the true powers
 // of 256 are used here, not the centred residues cs[].
+// the same without addend / message term and with the one-step recombination known to be exact
+// (Regev and SIS: most row blocks of most launches) -- 11 instructions
+template <int S>
+__device__ __forceinline__ uint32_t qf_epi_f64_plain(int a0, int a1, int a2, int a3, const QfGemmArgs &a) {
+    static_assert(S >= 1 && S <= 4, "one-digit operands: S = LA <= 4");
+    double x = (double)a0;
+    if constexpr (S >= 2) x = __builtin_fma((double)a1, 256.0, x);
+    if constexpr (S >= 3) {
+        double hi = (double)a2;
+        if constexpr (S >= 4) hi = __builtin_fma((double)a3, 256.0, hi);
+        x = __builtin_fma(hi, 65536.0, x);
+    }
+    const double t = __builtin_rint(x * a.qinv);
+    const uint32_t r = (uint32_t)(int)__builtin_fma(-t, a.qd, x);
+    const uint32_t rq = r + a.mod.q;
+    return r < rq ? r : rq;
+}
 template <int S>
 __device__ __forceinline__ uint32_t qf_epi_f64(int a0, int a1, int a2, int a3, double extra, const QfGemmArgs &a) {
     static_assert(S >= 1 && S <= 4, "one-digit operands: S = LA <= 4");
