@@ -179,3 +179,33 @@ def test_asm_window_checker_flags_a_touched_destination(tmp_path):
     bad2.write_text(cfg % "")
     r = subprocess.run([sys.executable, tool, str(bad2), "qf_gemm"], capture_output=True, text=True)
     assert r.returncode != 0 and "v[21]" in r.stdout
+
+
+def test_fp64_epilogue_arithmetic_is_exact():
+    """The arithmetic of qf_epi_f64 (crypto_amd/csrc/qf_gemm.h), restated in numpy float64 and checked against
+    Python integers at the bounds the launcher allows: accumulators up to 2^31 - 1 in magnitude, q up to 2^31 - 1,
+    one-step recombination while 257 * 65536 * |acc| + 2^34 < 2^52, the two-step form beyond."""
+    rng = np.random.default_rng(5)
+
+    def epi(a, extra, q, two_step):
+        qd, qinv = np.float64(q), np.float64(1.0) / np.float64(q)
+        x = a[0].astype(np.float64) + extra
+        x = a[1].astype(np.float64) * 256.0 + x              # each fma below is exact, so mul + add equals it
+        hi = a[3].astype(np.float64) * 256.0 + a[2].astype(np.float64)
+        if two_step:
+            hi = hi - np.rint(hi * qinv) * qd
+        x = hi * 65536.0 + x
+        t = np.rint(x * qinv)
+        r = (x - t * qd).astype(np.int64)                    # fma(-t, q, x): t*q < 2^53, the difference is exact
+        return np.where(r < 0, r + q, r)
+
+    for q in (2, 3, 257, 16777213, 1073741789, 2147483629, 2147483647):
+        for amax, two_step in ((2**25, False), (2**27 - 1, False), (2**31 - 1, True), (2**20, True)):
+            if not two_step:
+                assert amax * 257 * 65536 + 2**34 < 2**52
+            a = rng.integers(-amax, amax + 1, size=(4, 4000), dtype=np.int64)
+            a[:, 0], a[:, 1] = amax, -amax                   # the corners
+            extra = rng.integers(0, 2 * q, size=4000).astype(np.float64)
+            got = epi(a, extra, q, two_step)
+            want = [(int(a[0, i]) + 256 * int(a[1, i]) + 65536 * (int(a[2, i]) + 256 * int(a[3, i])) + int(extra[i])) % q for i in range(4000)]
+            assert got.tolist() == want, (q, amax, two_step)
