@@ -498,12 +498,25 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a, const uint32_t
             const uint32_t kt2 = kt + 2 < ntiles ? kt + 2 : ntiles - 1;
 #pragma unroll
             for (int ks = 0; ks < QF_KS; ks++) {
+#ifndef QF_ABL_NOPRIO
+                // The two waves of a SIMD take turns at the higher issue priority, half a barrier interval
+                // each.  Left alone the arbiter favours the older wave (0-3) all the time: it finishes its
+                // k-steps early, idles at the barrier for a third of the loop (per-wave stamps: 20.4 k of
+                // 60.6 k cycles, waves 4-7: 1.7 k) and leaves its partner alone on the pipe, where one wave
+                // cannot hide its own LDS latency.
+                if (ks == 0) { if (wave >= QF_NW / 2) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+                if (ks == 2) { if (wave >= QF_NW / 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#endif
                 if (ks == 2) {
                     // mid-tile: tile t+1 has landed for everyone, tile t-1's buffer is free
+                    QF_T(ta)
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    QF_T(tb)
 #ifndef QF_ABL_NOBAR
                     __builtin_amdgcn_s_barrier();
 #endif
+                    QF_T(tc)
+                    QF_ACC(s_vm, ta, tb) QF_ACC(s_bar, tb, tc)
                     QF_LOAD_AT(1, kt1)
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -642,6 +655,7 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a, const uint32_t
     }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail DMAs must not outlive the workgroup's LDS
+    __builtin_amdgcn_s_setprio(0);
     QF_T(tl1)
     QF_ACC(s_loop, tl0, tl1)
 
@@ -921,6 +935,11 @@ __device__ __forceinline__ void qf_gemm_body16(const QfGemmArgs &a, const uint32
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const int sp = g / H, rem = g % H, fi = rem / 2, kg = rem % 2, slot = g % D;
+#ifndef QF_ABL_NOPRIO
+            // the two waves of a SIMD take turns at the higher issue priority (see qf_gemm_body)
+            if (g == 0) { if (wave >= QF_NW / 2) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+            if (g == H) { if (wave >= QF_NW / 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#endif
             if (g == H) {
                 // mid-tile: tile t+1 has landed for everyone, tile t-1's buffer is free
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -974,6 +993,7 @@ __device__ __forceinline__ void qf_gemm_body16(const QfGemmArgs &a, const uint32
 #pragma unroll
     for (int g = 0; g < D; g++) asm volatile("" : "+v"(ring[g]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail DMAs must not outlive the workgroup's LDS
+    __builtin_amdgcn_s_setprio(0);
     }
 
     // ---- epilogue.  D tile of a 16x16x64 MFMA: lane holds key row 16*kg + lc of the block, messages

@@ -37,3 +37,6 @@ print("shares of total: loop %.3f vm %.3f bar %.3f at %.3f epi %.3f" % tuple(d[:
 print("kernel span cycles (max end - min start): %d" % (d[:, 6].max() - d[:, 5].min()))
 print("epilogue split: addend-load wait %.0f  compute+store issue %.0f  final store drain %.0f (cycles per wave, 100 MHz s_memtime ticks x clock ratio)" %
       (d2[:, 0].mean(), d2[:, 1].mean(), d2[:, 2].mean()))
+print("barrier wait by wave slot 0..7:", " ".join("%.0f" % d[w::8, 2].mean() for w in range(8)))
+print("loop cycles by wave slot 0..7: ", " ".join("%.0f" % d[w::8, 0].mean() for w in range(8)))
+print("epilogue by wave slot 0..7:    ", " ".join("%.0f" % d[w::8, 4].mean() for w in range(8)))
