@@ -70,6 +70,10 @@ SYMBOLS = {
     "qf_sample_bits_dev": (_i, [_vp, _u64, _u32, _u64, _u64, _u32, _u32, _vp]),
     "qf_sample_noise_dev": (_i, [_vp, _u64, _u32, _u64, _u64, _u32, _u32, _vp]),
     "qf_sample_discrete_gauss_dev": (_i, [_vp, _u64, _u32, _u64, _u64, _u32, _u32, C.c_double, _vp]),
+    "qf_sample_uniform_keyed_dev": (_i, [_vp, C.c_char_p, _u64, _u32, _u64, _u64, _u32, _vp]),
+    "qf_sample_bits_keyed_dev": (_i, [_vp, C.c_char_p, _u64, _u32, _u64, _u64, _u32, _u32, _vp]),
+    "qf_sample_noise_keyed_dev": (_i, [_vp, C.c_char_p, _u64, _u32, _u64, _u64, _u32, _u32, _vp]),
+    "qf_sample_discrete_gauss_keyed_dev": (_i, [_vp, C.c_char_p, _u64, _u32, _u64, _u64, _u32, _u32, C.c_double, _vp]),
     "qf_set_timing": (_i, [_vp, _i]),
     "qf_last_kernel_ms": (_i, [_vp, C.c_char_p, C.POINTER(C.c_float)]),
 }

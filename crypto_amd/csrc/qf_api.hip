@@ -400,6 +400,7 @@ int qf_matvec_modq_dev(qf_ctx *ctx, const qf_key *key, const uint32_t *x_dev, ui
 }
 int qf_vecmat_modq_dev(qf_ctx *ctx, const qf_key *key, const uint32_t *x_dev, uint32_t *y_dev) {
     if (!ctx || !key || !x_dev || !y_dev) return QF_ERR_ARG;
+    if (key->device != ctx->device) return qf_fail(ctx, QF_ERR_ARG, "vecmat: key lives on another device");
     QF_BIND(ctx);
     return qf_launch_vecmat(ctx, key, x_dev, y_dev);
 }
@@ -420,6 +421,7 @@ int qf_matvec_modq_static_dev(qf_ctx *ctx, const qf_key *key, const uint32_t *x_
 }
 static int vec_host(qf_ctx *ctx, const qf_key *key, const uint32_t *x_host, uint32_t *y_host, bool trans) {
     if (!ctx || !key || !x_host || !y_host) return QF_ERR_ARG;
+    if (key->device != ctx->device) return qf_fail(ctx, QF_ERR_ARG, "matvec: key lives on another device");
     QF_BIND(ctx);
     uint32_t nin = trans ? key->rows : key->cols, nout = trans ? key->cols : key->rows;
     // staging pooled in the context (grown on demand): single-message calls allocate nothing in steady state
@@ -624,27 +626,64 @@ int qf_hash_to_mat_zq_sha256_dev(qf_ctx *ctx, const uint8_t *msgs_dev, const uin
 }
 
 // ------------------------------------------------------------------ generator
-static uint64_t gen_base(uint64_t seed, uint32_t stream) { return seed ^ ((uint64_t)stream << 48); }
-int qf_sample_uniform_dev(qf_ctx *ctx, uint64_t seed, uint32_t stream, uint64_t first, uint64_t count, uint32_t q, uint32_t *out_dev) {
+// seeded: SplitMix64 under seed ^ (stream << 48); keyed: ChaCha20 under a 256-bit key, nonce ^ (stream << 48)
+static QfGen gen_seeded(uint64_t seed, uint32_t stream) {
+    QfGen g;
+    memset(&g, 0, sizeof g);
+    g.base = seed ^ ((uint64_t)stream << 48);
+    return g;
+}
+static QfGen gen_keyed(const uint8_t *key, uint64_t nonce, uint32_t stream) {
+    QfGen g = gen_seeded(nonce, stream);
+    for (int i = 0; i < 8; i++)
+        g.key[i] = (uint32_t)key[4 * i] | ((uint32_t)key[4 * i + 1] << 8) | ((uint32_t)key[4 * i + 2] << 16) | ((uint32_t)key[4 * i + 3] << 24);
+    g.keyed = 1;
+    return g;
+}
+static int sample_uniform(qf_ctx *ctx, const QfGen &g, uint64_t first, uint64_t count, uint32_t q, uint32_t *out_dev) {
     if (!ctx || (!out_dev && count)) return QF_ERR_ARG;
     if (q < 1) return qf_fail(ctx, QF_ERR_MODULUS, "sample: bound must be positive");
     QF_BIND(ctx);
-    return qf_launch_sample_uniform(ctx, gen_base(seed, stream), first, count, q, out_dev);
+    return qf_launch_sample_uniform(ctx, g, first, count, q, out_dev);
 }
-int qf_sample_bits_dev(qf_ctx *ctx, uint64_t seed, uint32_t stream, uint64_t first_row, uint64_t rows, uint32_t cols,
-                       uint32_t stride_bytes, uint8_t *out_dev) {
+static int sample_bits(qf_ctx *ctx, const QfGen &g, uint64_t first_row, uint64_t rows, uint32_t cols, uint32_t stride_bytes, uint8_t *out_dev) {
     if (!ctx || (!out_dev && rows)) return QF_ERR_ARG;
     if (stride_bytes % 4 || (uint64_t)stride_bytes * 8 < cols) return qf_fail(ctx, QF_ERR_DIM, "sample bits: stride must be a multiple of 4 bytes covering cols bits");
     QF_BIND(ctx);
-    return qf_launch_sample_bits(ctx, gen_base(seed, stream), first_row, rows, cols, stride_bytes, out_dev);
+    return qf_launch_sample_bits(ctx, g, first_row, rows, cols, stride_bytes, out_dev);
 }
-int qf_sample_noise_dev(qf_ctx *ctx, uint64_t seed, uint32_t stream, uint64_t first, uint64_t count, uint32_t q, uint32_t W, uint32_t *out_dev) {
+static int sample_noise(qf_ctx *ctx, const QfGen &g, uint64_t first, uint64_t count, uint32_t q, uint32_t W, uint32_t *out_dev) {
     if (!ctx || (!out_dev && count)) return QF_ERR_ARG;
     int rc = check_q(ctx, q);
     if (rc) return rc;
     if (W >= (1u << 30)) return qf_fail(ctx, QF_ERR_ARG, "sample noise: W too large");
     QF_BIND(ctx);
-    return qf_launch_sample_noise(ctx, gen_base(seed, stream), first, count, qf_make_mod(q), W, out_dev);
+    return qf_launch_sample_noise(ctx, g, first, count, qf_make_mod(q), W, out_dev);
+}
+int qf_sample_uniform_dev(qf_ctx *ctx, uint64_t seed, uint32_t stream, uint64_t first, uint64_t count, uint32_t q, uint32_t *out_dev) {
+    return sample_uniform(ctx, gen_seeded(seed, stream), first, count, q, out_dev);
+}
+int qf_sample_bits_dev(qf_ctx *ctx, uint64_t seed, uint32_t stream, uint64_t first_row, uint64_t rows, uint32_t cols,
+                       uint32_t stride_bytes, uint8_t *out_dev) {
+    return sample_bits(ctx, gen_seeded(seed, stream), first_row, rows, cols, stride_bytes, out_dev);
+}
+int qf_sample_noise_dev(qf_ctx *ctx, uint64_t seed, uint32_t stream, uint64_t first, uint64_t count, uint32_t q, uint32_t W, uint32_t *out_dev) {
+    return sample_noise(ctx, gen_seeded(seed, stream), first, count, q, W, out_dev);
+}
+int qf_sample_uniform_keyed_dev(qf_ctx *ctx, const uint8_t *key32, uint64_t nonce, uint32_t stream, uint64_t first, uint64_t count,
+                                uint32_t q, uint32_t *out_dev) {
+    if (!key32) return QF_ERR_ARG;
+    return sample_uniform(ctx, gen_keyed(key32, nonce, stream), first, count, q, out_dev);
+}
+int qf_sample_bits_keyed_dev(qf_ctx *ctx, const uint8_t *key32, uint64_t nonce, uint32_t stream, uint64_t first_row, uint64_t rows,
+                             uint32_t cols, uint32_t stride_bytes, uint8_t *out_dev) {
+    if (!key32) return QF_ERR_ARG;
+    return sample_bits(ctx, gen_keyed(key32, nonce, stream), first_row, rows, cols, stride_bytes, out_dev);
+}
+int qf_sample_noise_keyed_dev(qf_ctx *ctx, const uint8_t *key32, uint64_t nonce, uint32_t stream, uint64_t first, uint64_t count,
+                              uint32_t q, uint32_t W, uint32_t *out_dev) {
+    if (!key32) return QF_ERR_ARG;
+    return sample_noise(ctx, gen_keyed(key32, nonce, stream), first, count, q, W, out_dev);
 }
 
 // D_{Z,s}: rho_s(x) = exp(-pi x^2 / s^2) on |x| <= T = ceil(s * log2(n)) (GPV08 SampleZ's support with
@@ -676,8 +715,7 @@ static int build_cdt(qf_ctx *ctx, uint32_t n, double s) {
     ctx->cdt_len = (uint32_t)len; ctx->cdt_n = n; ctx->cdt_s = s;
     return QF_OK;
 }
-int qf_sample_discrete_gauss_dev(qf_ctx *ctx, uint64_t seed, uint32_t stream, uint64_t first, uint64_t count, uint32_t q,
-                                 uint32_t n, double s, uint32_t *out_dev) {
+static int sample_gauss(qf_ctx *ctx, const QfGen &g, uint64_t first, uint64_t count, uint32_t q, uint32_t n, double s, uint32_t *out_dev) {
     if (!ctx || (!out_dev && count)) return QF_ERR_ARG;
     int rc = check_q(ctx, q);
     if (rc) return rc;
@@ -685,8 +723,16 @@ int qf_sample_discrete_gauss_dev(qf_ctx *ctx, uint64_t seed, uint32_t stream, ui
     QF_BIND(ctx);
     rc = build_cdt(ctx, n, s);
     if (rc) return rc;
-    return qf_launch_sample_cdt(ctx, gen_base(seed, stream), first, count, qf_make_mod(q), ctx->cdt, ctx->cdt_len,
-                                -(int64_t)(ctx->cdt_len / 2), out_dev);
+    return qf_launch_sample_cdt(ctx, g, first, count, qf_make_mod(q), ctx->cdt, ctx->cdt_len, -(int64_t)(ctx->cdt_len / 2), out_dev);
+}
+int qf_sample_discrete_gauss_dev(qf_ctx *ctx, uint64_t seed, uint32_t stream, uint64_t first, uint64_t count, uint32_t q,
+                                 uint32_t n, double s, uint32_t *out_dev) {
+    return sample_gauss(ctx, gen_seeded(seed, stream), first, count, q, n, s, out_dev);
+}
+int qf_sample_discrete_gauss_keyed_dev(qf_ctx *ctx, const uint8_t *key32, uint64_t nonce, uint32_t stream, uint64_t first,
+                                       uint64_t count, uint32_t q, uint32_t n, double s, uint32_t *out_dev) {
+    if (!key32) return QF_ERR_ARG;
+    return sample_gauss(ctx, gen_keyed(key32, nonce, stream), first, count, q, n, s, out_dev);
 }
 
 // ------------------------------------------------------------------ timing

@@ -69,6 +69,40 @@ __device__ __forceinline__ uint32_t qf_rand_below(uint64_t base, uint64_t idx, u
     return (uint32_t)__umul64hi(qf_rand64(base, idx), (uint64_t)bound);
 }
 
+// ---- the generator behind every qf_sample_* entry point: SplitMix64 in counter mode under a 64-bit
+// seed (tests, benches, oracle parity), or -- the *_keyed_dev entry points, used whenever a host object
+// was constructed WITHOUT a seed -- ChaCha20 in counter mode under a 256-bit key: value(idx) = the first
+// 8 bytes (little-endian) of the ChaCha20 block with block counter idx (64-bit: state words 12, 13) and
+// nonce `base` (state words 14, 15).  A public matrix drawn from it reveals nothing about the secret
+// streams of the same key (SplitMix64's finaliser is a bijection of a 64-bit state: not a CSPRNG).
+struct QfGen {
+    uint64_t base;      // SplitMix64: seed ^ (stream << 48); ChaCha20: the 64-bit nonce, nonce ^ (stream << 48)
+    uint32_t key[8];
+    uint32_t keyed;
+    uint32_t pad;
+};
+#define QF_CHACHA_QR(a, b, c, d)                                         \
+    a += b; d ^= a; d = (d << 16) | (d >> 16); c += d; b ^= c; b = (b << 12) | (b >> 20); \
+    a += b; d ^= a; d = (d << 8) | (d >> 24);  c += d; b ^= c; b = (b << 7) | (b >> 25);
+__device__ __forceinline__ uint64_t qf_chacha64(const QfGen &g, uint64_t idx) {
+    const uint32_t c0 = 0x61707865u, c1 = 0x3320646eu, c2 = 0x79622d32u, c3 = 0x6b206574u;
+    uint32_t x0 = c0, x1 = c1, x2 = c2, x3 = c3, x4 = g.key[0], x5 = g.key[1], x6 = g.key[2], x7 = g.key[3],
+             x8 = g.key[4], x9 = g.key[5], x10 = g.key[6], x11 = g.key[7], x12 = (uint32_t)idx, x13 = (uint32_t)(idx >> 32),
+             x14 = (uint32_t)g.base, x15 = (uint32_t)(g.base >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        QF_CHACHA_QR(x0, x4, x8, x12) QF_CHACHA_QR(x1, x5, x9, x13) QF_CHACHA_QR(x2, x6, x10, x14) QF_CHACHA_QR(x3, x7, x11, x15)
+        QF_CHACHA_QR(x0, x5, x10, x15) QF_CHACHA_QR(x1, x6, x11, x12) QF_CHACHA_QR(x2, x7, x8, x13) QF_CHACHA_QR(x3, x4, x9, x14)
+    }
+    return (uint64_t)(x0 + c0) | ((uint64_t)(x1 + c1) << 32);
+}
+__device__ __forceinline__ uint64_t qf_gen64(const QfGen &g, uint64_t idx) {
+    return g.keyed ? qf_chacha64(g, idx) : qf_sm64(g.base + idx);   // wave-uniform branch
+}
+__device__ __forceinline__ uint32_t qf_gen_below(const QfGen &g, uint64_t idx, uint32_t bound) {
+    return (uint32_t)__umul64hi(qf_gen64(g, idx), (uint64_t)bound);
+}
+
 // 64-bit wave reductions (wave = 64 lanes)
 __device__ __forceinline__ uint64_t qf_wave_sum_u64(uint64_t v) {
 #pragma unroll

@@ -1165,9 +1165,8 @@ static int qf_gemm_dispatch_wn(qf_ctx *ctx, const QfGemmArgs &args) {
     constexpr int FRAGS = WN * QF_KS * LA;
     size_t lds = 3 * (size_t)FRAGS * 1024;
     static QfPerDevice attr;
-    if (attr.need(ctx->device))
-        QF_HIP(ctx, hipFuncSetAttribute((const void *)qf_gemm_kernel<LA, LB, WN, MW, BITS>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    QF_HIP(ctx, attr.once(ctx->device, [&] { return hipFuncSetAttribute((const void *)qf_gemm_kernel<LA, LB, WN, MW, BITS>,
+                                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }));
     uint64_t nmsgtiles = (args.B + 32 * QF_NW * MW - 1) / (32 * QF_NW * MW);
     dim3 grid((unsigned)nmsgtiles, (args.rb + WN - 1) / WN), block(QF_NW * 64);
     QfGemmArgs la = args;
@@ -1182,8 +1181,7 @@ template <int LA, int WN>
 static int qf_gemm_dispatch_packed(qf_ctx *ctx, const QfGemmArgs &args) {
     size_t lds = 3 * (size_t)WN * LA * QF_KS * 1024;
     static QfPerDevice attr;
-    if (attr.need(ctx->device))
-        QF_HIP(ctx, hipFuncSetAttribute((const void *)qf_gemm_packed_kernel<LA, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    QF_HIP(ctx, attr.once(ctx->device, [&] { return hipFuncSetAttribute((const void *)qf_gemm_packed_kernel<LA, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }));
     uint64_t nmsgtiles = (args.B + 32 * QF_NW - 1) / (32 * QF_NW);
     dim3 grid((unsigned)nmsgtiles, args.rb / WN), block(QF_NW * 64);   // rb = full blocks + 1, a multiple of WN here
     QfGemmArgs la = args;
@@ -1198,8 +1196,7 @@ template <int LA, int WN>
 static int qf_gemm_dispatch_packedx(qf_ctx *ctx, const QfGemmArgs &args) {
     size_t lds = 3 * ((size_t)WN * LA + 1) * QF_KS * 1024;
     static QfPerDevice attr;
-    if (attr.need(ctx->device))
-        QF_HIP(ctx, hipFuncSetAttribute((const void *)qf_gemm_packedx_kernel<LA, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    QF_HIP(ctx, attr.once(ctx->device, [&] { return hipFuncSetAttribute((const void *)qf_gemm_packedx_kernel<LA, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }));
     uint64_t nmsgtiles = (args.B + 32 * QF_NW - 1) / (32 * QF_NW);
     dim3 grid((unsigned)nmsgtiles, (args.rb - 1) / WN), block(QF_NW * 64);   // rb - 1 full blocks, a multiple of WN here
     QfGemmArgs la = args;

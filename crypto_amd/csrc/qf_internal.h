@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
+#include <mutex>
 #include <string>
 #include "../../include/qfgpu.h"
 #include "qf_device.h"
@@ -17,6 +19,7 @@ struct qf_ctx {
     size_t ws2_bytes = 0;
     void *mv_acc = nullptr;   // mat-vec cross-workgroup sums: one uint64 per padded row, all-zero between launches
     size_t mv_acc_bytes = 0;
+    bool mv_acc_dirty = false; // a launch over mv_acc failed: its words are cleared before the next one
     uint32_t *hostvec = nullptr;  // staging of the *_host single-message entry points (x then y)
     size_t hostvec_words = 0;
     uint32_t *flag = nullptr; // device error flag (range violations)
@@ -32,17 +35,24 @@ struct qf_ctx {
     float ms_gemm = -1.f, ms_ntt = -1.f, ms_matvec = -1.f, ms_decode = -1.f;
 };
 
-// per-device "already done" flags (function attributes such as the dynamic LDS limit are per device:
-// a process that drives several GPUs must set them on each)
+// per-device one-time set-up (function attributes such as the dynamic LDS limit are per device: a
+// process that drives several GPUs must set them on each).  Several contexts / threads may meet
+// here for one device: the work runs under a lock, and a device is marked only after its call
+// returned hipSuccess -- a failed attempt is retried by the next launch, and no thread can launch
+// with > 64 KiB of dynamic LDS before the attribute is in place.
 #define QF_MAX_DEVICES 64
 struct QfPerDevice {
-    bool done[QF_MAX_DEVICES] = {};
-    // true exactly when the caller still has to do the work for this device (devices beyond the table: always)
-    bool need(int device) {
-        if (device < 0 || device >= QF_MAX_DEVICES) return true;
-        if (done[device]) return false;
-        done[device] = true;
-        return true;
+    std::atomic<bool> done[QF_MAX_DEVICES] = {};
+    std::mutex mu;
+    template <class F>
+    hipError_t once(int device, F set) {
+        if (device < 0 || device >= QF_MAX_DEVICES) return set();   // beyond the table: every time
+        if (done[device].load(std::memory_order_acquire)) return hipSuccess;
+        std::lock_guard<std::mutex> lk(mu);
+        if (done[device].load(std::memory_order_relaxed)) return hipSuccess;
+        const hipError_t e = set();
+        if (e == hipSuccess) done[device].store(true, std::memory_order_release);
+        return e;
     }
 };
 
@@ -127,12 +137,12 @@ int qf_static_scratch_init(qf_ctx *ctx);   // resolves the per-device address of
 int qf_launch_dot_decode(qf_ctx *ctx, const uint32_t *w, uint32_t n, const QfMod &mod, const uint32_t *C,
                          uint64_t B, uint8_t *bits);
 // qf_sampler.hip
-int qf_launch_sample_uniform(qf_ctx *ctx, uint64_t base, uint64_t first, uint64_t count, uint32_t q, uint32_t *out);
-int qf_launch_sample_bits(qf_ctx *ctx, uint64_t base, uint64_t first_row, uint64_t rows, uint32_t cols,
+int qf_launch_sample_uniform(qf_ctx *ctx, QfGen base, uint64_t first, uint64_t count, uint32_t q, uint32_t *out);
+int qf_launch_sample_bits(qf_ctx *ctx, QfGen base, uint64_t first_row, uint64_t rows, uint32_t cols,
                           uint32_t stride_bytes, uint8_t *out);
-int qf_launch_sample_cdt(qf_ctx *ctx, uint64_t base, uint64_t first, uint64_t count, const QfMod &mod,
+int qf_launch_sample_cdt(qf_ctx *ctx, QfGen base, uint64_t first, uint64_t count, const QfMod &mod,
                          const uint64_t *thr_dev, uint32_t len, int64_t lo, uint32_t *out);
-int qf_launch_sample_noise(qf_ctx *ctx, uint64_t base, uint64_t first, uint64_t count, const QfMod &mod,
+int qf_launch_sample_noise(qf_ctx *ctx, QfGen base, uint64_t first, uint64_t count, const QfMod &mod,
                            uint32_t W, uint32_t *out);
 // qf_ntt.hip
 int qf_launch_ntt_forward_keys(qf_ctx *ctx, const qf_ring *ring, qf_rkey *rk);

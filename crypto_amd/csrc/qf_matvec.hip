@@ -4,6 +4,7 @@
 // of x); x^t*A and the decryption work on uint32 words with split 64-bit sums (low and high halves
 // of each 62-bit product summed separately, so nothing can overflow) reduced once per output.
 #include <cstdlib>
+#include <mutex>
 #include "qf_internal.h"
 
 #define MV_BLOCK 256
@@ -149,9 +150,11 @@ __global__ __launch_bounds__(MVP_THREADS) void qf_matvec_planes_kernel(QfMvpArgs
 #define QF_STATIC_ROWS 32768
 static __device__ __align__(256) unsigned long long qf_static_scratch[QF_STATIC_ROWS];
 static unsigned long long *g_static_ptr[QF_MAX_DEVICES];
+static std::mutex g_static_mu;   // two threads may create the first contexts of one device at once
 
 int qf_static_scratch_init(qf_ctx *ctx) {
     if (ctx->device < 0 || ctx->device >= QF_MAX_DEVICES) return qf_fail(ctx, QF_ERR_NOTSUP, "static scratch: device index out of range");
+    std::lock_guard<std::mutex> lk(g_static_mu);
     if (g_static_ptr[ctx->device]) return QF_OK;
     unsigned long long *p = nullptr;
     QF_HIP(ctx, hipGetSymbolAddress((void **)&p, HIP_SYMBOL(qf_static_scratch)));
@@ -215,8 +218,17 @@ int qf_launch_matvec(qf_ctx *ctx, const qf_key *key, const uint32_t *x, uint32_t
         QF_HIP(ctx, hipMalloc(&ctx->mv_acc, need));
         ctx->mv_acc_bytes = need;
         QF_HIP(ctx, hipMemsetAsync(ctx->mv_acc, 0, need, ctx->stream));
+        ctx->mv_acc_dirty = false;
     }
-    return mvp_run(ctx, key, x, y, (unsigned long long *)ctx->mv_acc);
+    // The kernel returns every word it used to zero -- IF it ran to its end.  After a launch that failed
+    // (or was refused) the words may hold half a handshake: clear them before they are trusted again.
+    if (ctx->mv_acc_dirty) {
+        QF_HIP(ctx, hipMemsetAsync(ctx->mv_acc, 0, ctx->mv_acc_bytes, ctx->stream));
+        ctx->mv_acc_dirty = false;
+    }
+    const int rc = mvp_run(ctx, key, x, y, (unsigned long long *)ctx->mv_acc);
+    if (rc) ctx->mv_acc_dirty = true;
+    return rc;
 }
 
 // No allocation anywhere on this path: the cross-workgroup sums live in qf_static_scratch (through

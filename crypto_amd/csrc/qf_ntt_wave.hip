@@ -465,11 +465,11 @@ static int wv_launch(qf_ctx *ctx, const qf_ring *ring, const QfRingArgs &a) {
     QfTimer t(ctx, &ctx->ms_ntt);
     if (lazy) {
         static QfPerDevice attr;
-        if (attr.need(ctx->device)) QF_HIP(ctx, hipFuncSetAttribute((const void *)qf_ring_wave_kernel<LG, MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        QF_HIP(ctx, attr.once(ctx->device, [&] { return hipFuncSetAttribute((const void *)qf_ring_wave_kernel<LG, MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }));
         hipLaunchKernelGGL((qf_ring_wave_kernel<LG, MODE, true>), dim3((unsigned)blocks), dim3(WV_THREADS), lds, ctx->stream, a);
     } else {
         static QfPerDevice attr;
-        if (attr.need(ctx->device)) QF_HIP(ctx, hipFuncSetAttribute((const void *)qf_ring_wave_kernel<LG, MODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        QF_HIP(ctx, attr.once(ctx->device, [&] { return hipFuncSetAttribute((const void *)qf_ring_wave_kernel<LG, MODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }));
         hipLaunchKernelGGL((qf_ring_wave_kernel<LG, MODE, false>), dim3((unsigned)blocks), dim3(WV_THREADS), lds, ctx->stream, a);
     }
     QF_HIP(ctx, hipGetLastError());

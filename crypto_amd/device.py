@@ -95,14 +95,17 @@ class Context:
     def _to_host(self, t: torch.Tensor) -> np.ndarray:
         t = t.detach()
         nbytes = t.numel() * t.element_size()
+        if t.is_cuda and self._stream != torch.cuda.current_stream(self.device):
+            self._stream.synchronize()                        # `.cpu()` below only orders behind torch's current stream
         if nbytes < 4096 or nbytes > self._PIN_BYTES or not t.is_contiguous() or not t.is_cuda:
             return t.cpu().numpy()
         pin = getattr(self, "_pin", None)
         if pin is None:
             pin = self._pin = torch.empty(self._PIN_BYTES, dtype=torch.uint8).pin_memory()
         stage = pin[:nbytes].view(t.dtype).view(t.shape)      # one staging buffer: copy, wait, copy out
-        stage.copy_(t, non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()
+        with torch.cuda.stream(self._stream):                 # behind the library's kernels: the CONTEXT's stream,
+            stage.copy_(t, non_blocking=True)                 # which need not be torch's current one
+        self._stream.synchronize()
         return stage.numpy().copy()
 
     def to_host_u32(self, t: torch.Tensor) -> np.ndarray:
@@ -222,28 +225,60 @@ class Context:
         _check(self.h, self.lib.qf_ring_create(self.h, n, q, C.byref(h)))
         return Ring(self, h)
 
-    # ---- seeded generator ----------------------------------------------------------------
+    # ---- counter-mode generator -----------------------------------------------------------
+    # `seed` is a 64-bit integer (SplitMix64: tests, benches, oracle parity) or a (key32, nonce) pair
+    # (ChaCha20 under a 256-bit key: what an object constructed WITHOUT a seed draws from).
+    @staticmethod
+    def _keyed(seed):
+        if isinstance(seed, tuple):
+            key, nonce = seed
+            key = bytes(key)
+            if len(key) != 32:
+                raise QfError(_lib.QF_ERR_ARG, "generator key must be 32 bytes")
+            return key, int(nonce) & 0xFFFFFFFFFFFFFFFF
+        return None
+
     def sample_uniform(self, seed, stream, first, count, q, out=None):
         out = out if out is not None else self.empty_u32(count)
-        _check(self.h, self.lib.qf_sample_uniform_dev(self.h, seed, stream, first, count, q, out.data_ptr()))
+        k = self._keyed(seed)
+        if k:
+            rc = self.lib.qf_sample_uniform_keyed_dev(self.h, k[0], k[1], stream, first, count, q, out.data_ptr())
+        else:
+            rc = self.lib.qf_sample_uniform_dev(self.h, seed, stream, first, count, q, out.data_ptr())
+        _check(self.h, rc)
         return out
 
     def sample_bits(self, seed, stream, first_row, rows, cols, stride=None, out=None):
         stride = stride or bit_stride(cols)
         out = out if out is not None else self.empty_u8(rows, stride)
-        _check(self.h, self.lib.qf_sample_bits_dev(self.h, seed, stream, first_row, rows, cols, stride, out.data_ptr()))
+        k = self._keyed(seed)
+        if k:
+            rc = self.lib.qf_sample_bits_keyed_dev(self.h, k[0], k[1], stream, first_row, rows, cols, stride, out.data_ptr())
+        else:
+            rc = self.lib.qf_sample_bits_dev(self.h, seed, stream, first_row, rows, cols, stride, out.data_ptr())
+        _check(self.h, rc)
         return out
 
     def sample_noise(self, seed, stream, first, count, q, W, out=None):
         out = out if out is not None else self.empty_u32(count)
-        _check(self.h, self.lib.qf_sample_noise_dev(self.h, seed, stream, first, count, q, W, out.data_ptr()))
+        k = self._keyed(seed)
+        if k:
+            rc = self.lib.qf_sample_noise_keyed_dev(self.h, k[0], k[1], stream, first, count, q, W, out.data_ptr())
+        else:
+            rc = self.lib.qf_sample_noise_dev(self.h, seed, stream, first, count, q, W, out.data_ptr())
+        _check(self.h, rc)
         return out
 
     def sample_discrete_gauss(self, seed, stream, first, count, q, n, s, out=None):
         """D_{Z,s} (center 0) mod q, the distribution of MatZq::sample_discrete_gauss(.., q, n, 0, s)
-        (regev.rs:356-363, lpr.rs:342-360): seeded, drawn on the device."""
+        (regev.rs:356-363, lpr.rs:342-360): drawn on the device."""
         out = out if out is not None else self.empty_u32(count)
-        _check(self.h, self.lib.qf_sample_discrete_gauss_dev(self.h, seed, stream, first, count, q, int(n), float(s), out.data_ptr()))
+        k = self._keyed(seed)
+        if k:
+            rc = self.lib.qf_sample_discrete_gauss_keyed_dev(self.h, k[0], k[1], stream, first, count, q, int(n), float(s), out.data_ptr())
+        else:
+            rc = self.lib.qf_sample_discrete_gauss_dev(self.h, seed, stream, first, count, q, int(n), float(s), out.data_ptr())
+        _check(self.h, rc)
         return out
 
 

@@ -1,13 +1,17 @@
 """Process-wide default device context and the randomness the scheme layer draws from.
 
-The reference samples from the OS's RNG at every call (e.g. regev.rs:352-364,401).  Here a scheme
-object owns a `Randomness`: a 64-bit seed + per-stream counters over the SplitMix64 counter-mode
-generator of include/qfgpu.h.  With an explicit `seed=` (tests, bench, oracle parity) every run --
-GPU path and CPU oracle alike -- consumes the same inputs; WITHOUT one, each object draws a fresh
-seed from os.urandom, so two default-constructed schemes never share keys or encryption
-randomness.  SplitMix64 is a benchmark/test generator, NOT a CSPRNG: the drop-in keeps the
-reference's arithmetic, and a deployment that needs confidentiality supplies its own randomness
-through the explicit-randomness arguments (`enc(pk, msg, x=...)`, `enc_batch(..., x_bits=...)`).
+The reference samples from the OS's CSPRNG at every call (e.g. regev.rs:352-364,401).  Here a scheme
+object owns a `Randomness`: per-stream counters over one of the two counter-mode generators of
+include/qfgpu.h.
+
+* With an explicit `seed=` (tests, bench, oracle parity): SplitMix64 under that 64-bit seed, so that
+  every run -- GPU path and CPU oracle alike -- consumes the same inputs.  SplitMix64 is NOT a CSPRNG:
+  its finaliser is a bijection of a 64-bit state, a published matrix A gives away the seed and with
+  it the secret streams.  An explicit seed is a statement that confidentiality is not wanted.
+* WITHOUT one (the default construction, the reference's behaviour): ChaCha20 under a fresh 256-bit
+  key from os.urandom (`qf_sample_*_keyed_dev`).  Public and secret streams of one object share the
+  key and differ in the nonce word; the public stream reveals nothing about the others.  `rng.seed`
+  is then the pair (key32, nonce).
 Streams: 1 uniform A / a, 2 secret, 3 x / r, 4 noise e, 5 messages, 6 free operands.
 """
 from __future__ import annotations
@@ -20,9 +24,9 @@ import numpy as np
 MASTER_SEED = 0x5146414C4C  # "QFALL": the seed tests and benches pass EXPLICITLY; never a default
 
 
-def fresh_seed() -> int:
-    """64 bits from the OS, for objects constructed without a seed."""
-    return int.from_bytes(os.urandom(8), "little")
+def fresh_key():
+    """(key32, nonce) for objects constructed without a seed: 256 bits from the OS's CSPRNG."""
+    return (os.urandom(32), 0)
 
 _default_ctx = None
 
@@ -47,7 +51,10 @@ class Randomness:
     """Counter-mode draws; each stream advances its own counter so draws never overlap."""
 
     def __init__(self, seed: Optional[int] = None, ctx=None):
-        self.seed = fresh_seed() if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF
+        if seed is None or isinstance(seed, tuple):
+            self.seed = fresh_key() if seed is None else (bytes(seed[0]), int(seed[1]))   # keyed: ChaCha20
+        else:
+            self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF                                   # seeded: SplitMix64
         self._ctx = ctx
         self.pos = {}
 

@@ -11,9 +11,10 @@
 // throw qfall::MathError.  Header-only; link against crypto_amd/lib/libqfgpu.so.  Nothing here
 // computes lattice arithmetic on the CPU: every product goes through the C ABI.
 //
-// Randomness: the reference samples from an unseeded RNG (regev.rs:352-364,401).  Here every
-// scheme object owns a counter-mode SplitMix64 stream set (qfgpu.h "seeded generator"), so that
-// runs are reproducible and comparable with the oracle; explicit randomness can be passed to enc.
+// Randomness: the reference samples from the OS's CSPRNG (regev.rs:352-364,401).  Here every scheme
+// object owns a counter-mode stream set (qfgpu.h "seeded generator"): under an explicit 64-bit seed
+// SplitMix64 (reproducible, comparable with the oracle, NOT confidential), and -- the default
+// construction -- ChaCha20 under a fresh 256-bit key from the OS; explicit randomness can be passed to enc.
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -32,15 +33,28 @@ struct Panic : std::runtime_error { using std::runtime_error::runtime_error; };
 struct MathError : std::runtime_error { using std::runtime_error::runtime_error; };
 
 constexpr uint64_t MASTER_SEED = 0x5146414C4CULL;  // "QFALL": what tests and benches pass EXPLICITLY; never a default
-// Seed of an object constructed without one: 64 fresh bits from the OS, so that two default-constructed
-// schemes never share keys or encryption randomness (the reference draws OS randomness at every call,
-// regev.rs:352-364,401).  The generator behind it (SplitMix64 in counter mode, include/qfgpu.h) is a
-// benchmark/test generator, not a CSPRNG: a deployment that needs confidentiality passes its own
-// randomness through the explicit-randomness arguments (enc(pk, msg, &x), enc_batch(.., x_bits)).
-inline uint64_t fresh_seed() {
-    std::random_device rd;
-    return ((uint64_t)rd() << 32) ^ (uint64_t)rd();
-}
+// What a scheme's generator runs under.  An explicit 64-bit seed selects SplitMix64 in counter mode: a
+// benchmark/test generator whose state can be recovered from a published matrix -- passing one is a
+// statement that confidentiality is not wanted.  Seed::fresh(), the default of every constructor,
+// selects ChaCha20 under 256 bits from the OS (std::random_device reads the OS's CSPRNG on Linux), as
+// the reference draws OS randomness at every call (regev.rs:352-364,401): the public matrix then
+// reveals nothing about the secret, noise or encryption streams of the same object.
+struct Seed {
+    bool keyed = false;
+    uint64_t seed = 0;       // SplitMix64 seed, or the ChaCha20 nonce
+    uint8_t key[32] = {0};   // ChaCha20 key (keyed only)
+    Seed(uint64_t s) : seed(s) {}   // implicit on purpose: Regev(dev, n, m, q, alpha, MASTER_SEED)
+    static Seed fresh() {
+        Seed k(0);
+        k.keyed = true;
+        std::random_device rd;
+        for (int i = 0; i < 32; i += 4) {
+            const uint32_t w = rd();
+            std::memcpy(k.key + i, &w, 4);
+        }
+        return k;
+    }
+};
 
 // ---------------------------------------------------------------------------------------------
 // value types at the seam (qfall-math MatZq / MatZ / PolynomialRingZq / MatPolyOverZ)
@@ -184,41 +198,56 @@ class DevKey {  // MatZq resident on the device (qf_key)
 // seeded draws (streams: 1 uniform A/a, 2 secret, 3 x/r, 4 noise e, 5 messages, 6 free operands)
 class Randomness {
   public:
-    Randomness(const Device &d, uint64_t seed = fresh_seed()) : dev_(&d), seed_(seed) {}
-    uint64_t seed() const { return seed_; }
+    Randomness(const Device &d, Seed seed = Seed::fresh()) : dev_(&d), seed_(seed) {}
+    const Seed &seed() const { return seed_; }
     uint64_t take(uint32_t stream, uint64_t count) { uint64_t f = pos_[stream & 15]; pos_[stream & 15] += count; return f; }
-    std::vector<uint32_t> uniform(uint32_t stream, uint64_t count, uint32_t q) {
-        DevBuf<uint32_t> b(*dev_, count);
-        dev_->check(qf_sample_uniform_dev(dev_->ctx(), seed_, stream, take(stream, count), count, q, b.get()));
-        return b.download();
+    // ---- draws left in device memory (key generation keeps A, s and e there)
+    void uniform_dev(uint32_t stream, uint64_t count, uint32_t q, uint32_t *out_dev) {
+        const uint64_t f = take(stream, count);
+        dev_->check(seed_.keyed ? qf_sample_uniform_keyed_dev(dev_->ctx(), seed_.key, seed_.seed, stream, f, count, q, out_dev)
+                                : qf_sample_uniform_dev(dev_->ctx(), seed_.seed, stream, f, count, q, out_dev));
+    }
+    void gauss_dev(uint32_t stream, uint64_t count, uint32_t q, uint32_t n, double s, uint32_t *out_dev) {
+        const uint64_t f = take(stream, count);
+        dev_->check(seed_.keyed ? qf_sample_discrete_gauss_keyed_dev(dev_->ctx(), seed_.key, seed_.seed, stream, f, count, q, n, s, out_dev)
+                                : qf_sample_discrete_gauss_dev(dev_->ctx(), seed_.seed, stream, f, count, q, n, s, out_dev));
     }
     // chi: D_{Z,s} as MatZq::sample_discrete_gauss(.., q, n, 0, s) draws it (regev.rs:356-363,
     // lpr.rs:342-360) -- the schemes select it with (n, alpha*q) when they are constructed -- or, after
     // use_irwin_hall(), the benchmark generator's bounded stand-in (sum of 4 uniforms in [-W, W])
     void use_discrete_gauss(uint32_t n, double s) { gauss_n_ = n; gauss_s_ = s; }
     void use_irwin_hall() { gauss_n_ = 0; }
-    std::vector<uint32_t> noise(uint32_t stream, uint64_t count, uint32_t q, uint32_t W) {
+    void noise_dev(uint32_t stream, uint64_t count, uint32_t q, uint32_t W, uint32_t *out_dev) {
+        if (gauss_n_) return gauss_dev(stream, count, q, gauss_n_, gauss_s_, out_dev);
+        const uint64_t f = take(stream, count);
+        dev_->check(seed_.keyed ? qf_sample_noise_keyed_dev(dev_->ctx(), seed_.key, seed_.seed, stream, f, count, q, W, out_dev)
+                                : qf_sample_noise_dev(dev_->ctx(), seed_.seed, stream, f, count, q, W, out_dev));
+    }
+    void bits_dev(uint32_t stream, uint64_t rows, uint32_t cols, uint32_t stride, uint8_t *out_dev) {
+        const uint64_t f = take(stream, rows);
+        dev_->check(seed_.keyed ? qf_sample_bits_keyed_dev(dev_->ctx(), seed_.key, seed_.seed, stream, f, rows, cols, stride, out_dev)
+                                : qf_sample_bits_dev(dev_->ctx(), seed_.seed, stream, f, rows, cols, stride, out_dev));
+    }
+    // ---- the same draws brought to the host
+    std::vector<uint32_t> uniform(uint32_t stream, uint64_t count, uint32_t q) {
         DevBuf<uint32_t> b(*dev_, count);
-        if (gauss_n_)
-            dev_->check(qf_sample_discrete_gauss_dev(dev_->ctx(), seed_, stream, take(stream, count), count, q, gauss_n_, gauss_s_, b.get()));
-        else
-            dev_->check(qf_sample_noise_dev(dev_->ctx(), seed_, stream, take(stream, count), count, q, W, b.get()));
+        uniform_dev(stream, count, q, b.get());
         return b.download();
     }
-    // the same draws left in device memory (key generation keeps A, s and e there)
-    void uniform_dev(uint32_t stream, uint64_t count, uint32_t q, uint32_t *out_dev) {
-        dev_->check(qf_sample_uniform_dev(dev_->ctx(), seed_, stream, take(stream, count), count, q, out_dev));
+    std::vector<uint32_t> gauss(uint32_t stream, uint64_t count, uint32_t q, uint32_t n, double s) {
+        DevBuf<uint32_t> b(*dev_, count);
+        gauss_dev(stream, count, q, n, s, b.get());
+        return b.download();
     }
-    void noise_dev(uint32_t stream, uint64_t count, uint32_t q, uint32_t W, uint32_t *out_dev) {
-        if (gauss_n_)
-            dev_->check(qf_sample_discrete_gauss_dev(dev_->ctx(), seed_, stream, take(stream, count), count, q, gauss_n_, gauss_s_, out_dev));
-        else
-            dev_->check(qf_sample_noise_dev(dev_->ctx(), seed_, stream, take(stream, count), count, q, W, out_dev));
+    std::vector<uint32_t> noise(uint32_t stream, uint64_t count, uint32_t q, uint32_t W) {
+        DevBuf<uint32_t> b(*dev_, count);
+        noise_dev(stream, count, q, W, b.get());
+        return b.download();
     }
     std::vector<uint32_t> bits(uint32_t stream, uint32_t count) {  // MatZ::sample_uniform(m,1,0,2)
         const uint32_t stride = ((count + 127) / 128) * 16;
         DevBuf<uint8_t> b(*dev_, stride);
-        dev_->check(qf_sample_bits_dev(dev_->ctx(), seed_, stream, take(stream, 1), 1, count, stride, b.get()));
+        bits_dev(stream, 1, count, stride, b.get());
         std::vector<uint8_t> p = b.download();
         std::vector<uint32_t> out(count);
         for (uint32_t i = 0; i < count; i++) out[i] = (p[i >> 3] >> (i & 7)) & 1u;
@@ -227,7 +256,7 @@ class Randomness {
 
   private:
     const Device *dev_;
-    uint64_t seed_;
+    Seed seed_;
     uint64_t pos_[16] = {0};
     uint32_t gauss_n_ = 0;
     double gauss_s_ = 0.0;
@@ -319,7 +348,7 @@ class Regev : public PKEncryptionScheme<Regev, MatZq, MatZq, MatZq> {
   public:
     uint32_t n, m, q;
     double alpha;
-    Regev(const Device &d, uint32_t n_, uint32_t m_, uint32_t q_, double alpha_, uint64_t seed = fresh_seed())
+    Regev(const Device &d, uint32_t n_, uint32_t m_, uint32_t q_, double alpha_, Seed seed = Seed::fresh())
         : n(n_), m(m_), q(q_), alpha(alpha_), dev(&d), rng(d, seed) {            // Regev::new regev.rs:87-99
         if (q <= 1) throw Panic("modulus must be > 1");
         default_noise(rng, n, alpha * q);
@@ -403,7 +432,7 @@ class DualRegev : public PKEncryptionScheme<DualRegev, MatZq, MatZ, MatZq> {
   public:
     uint32_t n, m, q;
     double alpha;
-    DualRegev(const Device &d, uint32_t n_, uint32_t m_, uint32_t q_, double alpha_, uint64_t seed = fresh_seed())
+    DualRegev(const Device &d, uint32_t n_, uint32_t m_, uint32_t q_, double alpha_, Seed seed = Seed::fresh())
         : n(n_), m(m_), q(q_), alpha(alpha_), dev(&d), rng(d, seed) { if (q <= 1) throw Panic("modulus must be > 1"); default_noise(rng, n, alpha * q); }
     static DualRegev default_(const Device &d) { return DualRegev(d, 13, 154, 1427, 0.01); }
     static DualRegev new_from_n(const Device &d, uint32_t n) {   // dual_regev.rs:122-201 repeats regev.rs
@@ -470,7 +499,7 @@ class LPR : public PKEncryptionScheme<LPR, MatZq, MatZq, MatZq> {
   public:
     uint32_t n, q;
     double alpha;
-    LPR(const Device &d, uint32_t n_, uint32_t q_, double alpha_, uint64_t seed = fresh_seed())
+    LPR(const Device &d, uint32_t n_, uint32_t q_, double alpha_, Seed seed = Seed::fresh())
         : n(n_), q(q_), alpha(alpha_), dev(&d), rng(d, seed) { if (q <= 1) throw Panic("modulus must be > 1"); default_noise(rng, n, alpha * q); }
     static LPR default_(const Device &d) { return LPR(d, 10, 983, 0.0072); }            // lpr.rs:306-312
     static LPR secure128(const Device &d) { return LPR(d, 500, 76859609, 0.000005); }   // lpr.rs:290-292
@@ -582,7 +611,7 @@ class RingLPR : public PKEncryptionScheme<RingLPR, RingPair, PolynomialRingZq, R
   public:
     uint32_t n, q;
     double alpha;
-    RingLPR(const Device &d, uint32_t n_, uint32_t q_, double alpha_, uint64_t seed = fresh_seed())
+    RingLPR(const Device &d, uint32_t n_, uint32_t q_, double alpha_, Seed seed = Seed::fresh())
         : n(n_), q(q_), alpha(alpha_), dev(&d), rng(d, seed), ring(d, n_, q_) { default_noise(rng, n, alpha * q); }
     static RingLPR default_(const Device &d) { return RingLPR(d, 16, 2399, 0.0039); }             // ring_lpr.rs:343-345
     static RingLPR secure128(const Device &d) { return RingLPR(d, 512, 92897729, 0.000005); }     // ring_lpr.rs:312-314
@@ -697,7 +726,7 @@ class RegevWithDiscreteGaussianRegularity
     : public PKEncryptionScheme<RegevWithDiscreteGaussianRegularity, GaussPublicKey, MatZq, GaussCipher> {
   public:
     GaussRegularityParams pp;
-    RegevWithDiscreteGaussianRegularity(const Device &d, uint32_t n, uint32_t m, uint32_t q, double r, double alpha, uint64_t seed = fresh_seed())
+    RegevWithDiscreteGaussianRegularity(const Device &d, uint32_t n, uint32_t m, uint32_t q, double r, double alpha, Seed seed = Seed::fresh())
         : pp{n, m, q, r, alpha}, dev(&d), rng(d, seed) { if (q <= 1) throw Panic("modulus must be > 1"); }
     static RegevWithDiscreteGaussianRegularity default_(const Device &d) { return {d, 2, 16, 443, 4, 1.0 / 64}; }             // :329-338
     static RegevWithDiscreteGaussianRegularity secure128(const Device &d) { return {d, 350, 5248, 29892991, 12.357, 0.00009}; }  // :312-314
@@ -739,7 +768,7 @@ class RegevWithDiscreteGaussianRegularity
         MatZq K = stacked(pk);
         const uint64_t B = msg_bits.size();
         DevBuf<uint32_t> E(*dev, B * pp.m), out(*dev, B * (pp.n + 1));
-        dev->check(qf_sample_discrete_gauss_dev(dev->ctx(), rng.seed(), 3, rng.take(3, B * pp.m), B * pp.m, pp.q, pp.n, pp.r, E.get()));
+        rng.gauss_dev(3, B * pp.m, pp.q, pp.n, pp.r, E.get());
         qf_key *k = dev->cached_key(K);
         DevBuf<uint8_t> dm(*dev, msg_bits);
         dev->check(qf_matmul_modq_dev(dev->ctx(), k, E.get(), QF_X_U32, (size_t)pp.m * 4, 0, B, nullptr, dm.get(), out.get()));
@@ -754,9 +783,7 @@ class RegevWithDiscreteGaussianRegularity
 
   private:
     std::vector<uint32_t> gauss(uint32_t stream, uint64_t count, double s) {
-        DevBuf<uint32_t> b(*dev, count);
-        dev->check(qf_sample_discrete_gauss_dev(dev->ctx(), rng.seed(), stream, rng.take(stream, count), count, pp.q, pp.n, s, b.get()));
-        return b.download();
+        return rng.gauss(stream, count, pp.q, pp.n, s);
     }
     MatZq stacked(const GaussPublicKey &pk) const {   // K = [A ; p^t]
         if (pk.a.q != pp.q || pk.v.q != pp.q) throw Panic("mismatching modulus between scheme and key");
@@ -774,7 +801,7 @@ class DualRegevWithDiscreteGaussianRegularity
     : public PKEncryptionScheme<DualRegevWithDiscreteGaussianRegularity, GaussPublicKey, MatZq, GaussCipher> {
   public:
     GaussRegularityParams pp;
-    DualRegevWithDiscreteGaussianRegularity(const Device &d, uint32_t n, uint32_t m, uint32_t q, double r, double alpha, uint64_t seed = fresh_seed())
+    DualRegevWithDiscreteGaussianRegularity(const Device &d, uint32_t n, uint32_t m, uint32_t q, double r, double alpha, Seed seed = Seed::fresh())
         : pp{n, m, q, r, alpha}, dev(&d), rng(d, seed) { if (q <= 1) throw Panic("modulus must be > 1"); }
     static DualRegevWithDiscreteGaussianRegularity default_(const Device &d) { return {d, 2, 16, 443, 4, 1.0 / 64}; }
     static DualRegevWithDiscreteGaussianRegularity secure128(const Device &d) { return {d, 350, 5248, 29892991, 12.357, 0.00009}; }
@@ -814,9 +841,7 @@ class DualRegevWithDiscreteGaussianRegularity
 
   private:
     std::vector<uint32_t> gauss(uint32_t stream, uint64_t count, double s) {
-        DevBuf<uint32_t> b(*dev, count);
-        dev->check(qf_sample_discrete_gauss_dev(dev->ctx(), rng.seed(), stream, rng.take(stream, count), count, pp.q, pp.n, s, b.get()));
-        return b.download();
+        return rng.gauss(stream, count, pp.q, pp.n, s);
     }
     MatZq joined(const GaussPublicKey &pk) const {   // K = [A | u]
         if (pk.a.q != pp.q || pk.v.q != pp.q) throw Panic("mismatching modulus between scheme and key");
@@ -874,7 +899,7 @@ class SISHash {
   public:
     MatZq key;
     SISHash(const Device &d, MatZq k) : key(std::move(k)), dev(&d) {}
-    static SISHash gen(const Device &d, long n, uint32_t m, uint32_t q, uint64_t seed = fresh_seed()) {  // sis.rs:79-93
+    static SISHash gen(const Device &d, long n, uint32_t m, uint32_t q, Seed seed = Seed::fresh()) {  // sis.rs:79-93
         if (n < 1) throw MathError("n must be chosen bigger than 0.");
         Randomness rng(d, seed);
         MatZq A((uint32_t)n, m, q);

@@ -237,6 +237,25 @@ int qf_sample_noise_dev(qf_ctx *ctx, uint64_t seed, uint32_t stream, uint64_t fi
 int qf_sample_discrete_gauss_dev(qf_ctx *ctx, uint64_t seed, uint32_t stream, uint64_t first, uint64_t count,
                                  uint32_t q, uint32_t n, double s, uint32_t *out_dev);
 
+/* The same four samplers under a 256-bit KEY instead of a 64-bit seed -- what a host object constructed
+ * WITHOUT a seed draws from.  The reference takes every sample from the OS CSPRNG (regev.rs:352-364,401);
+ * SplitMix64 above is a test/bench generator whose 64-bit state can be recovered from a published
+ * matrix, so it must never produce a secret next to a public value.  Here
+ *   value(stream, idx) = first 8 bytes, little-endian, of the ChaCha20 block (20 rounds, D. J. Bernstein's
+ *   64-bit-counter form) with key key32, block counter idx (state words 12-13) and nonce
+ *   nonce ^ (stream << 48) (state words 14-15),
+ * and everything after `value` (multiply-high, bit rows, Irwin-Hall sum, inversion table) is as above.
+ * key32: 32 bytes from the host's CSPRNG (getrandom / os.urandom / std::random_device), read during the
+ * call only.  oracle/qf_oracle.c restates it (pinned by RFC 7539's block test vector). */
+int qf_sample_uniform_keyed_dev(qf_ctx *ctx, const uint8_t *key32, uint64_t nonce, uint32_t stream, uint64_t first,
+                                uint64_t count, uint32_t q, uint32_t *out_dev);
+int qf_sample_bits_keyed_dev(qf_ctx *ctx, const uint8_t *key32, uint64_t nonce, uint32_t stream, uint64_t first_row,
+                             uint64_t rows, uint32_t cols, uint32_t stride_bytes, uint8_t *out_dev);
+int qf_sample_noise_keyed_dev(qf_ctx *ctx, const uint8_t *key32, uint64_t nonce, uint32_t stream, uint64_t first,
+                              uint64_t count, uint32_t q, uint32_t W, uint32_t *out_dev);
+int qf_sample_discrete_gauss_keyed_dev(qf_ctx *ctx, const uint8_t *key32, uint64_t nonce, uint32_t stream, uint64_t first,
+                                       uint64_t count, uint32_t q, uint32_t n, double s, uint32_t *out_dev);
+
 /* ------------------------------------------------------------------ introspection for benches
  * Average duration (ms) of the LAST launch of the dominant kernel of the named op, measured
  * with HIP events on the context's stream when timing is enabled. */

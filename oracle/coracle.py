@@ -35,6 +35,8 @@ def lib():
         _lib = C.CDLL(_SO)
         _lib.qfo_rand64.restype = C.c_uint64
         _lib.qfo_rand64.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64]
+        _lib.qfo_rand64_keyed.restype = C.c_uint64
+        _lib.qfo_rand64_keyed.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint64]
         _lib.qfo_find_psi.restype = C.c_uint32
         _lib.qfo_hash_to_zq.restype = C.c_uint32
         _lib.qfo_decide_bit.restype = C.c_uint32
@@ -52,6 +54,8 @@ def _u32(a):
 
 
 def sample_uniform(seed, stream, first, count, q):
+    if isinstance(seed, tuple):          # (key32, nonce): the keyed generator
+        return sample_uniform_keyed(seed[0], seed[1], stream, first, count, q)
     out = np.empty(count, np.uint32)
     lib().qfo_sample_uniform(C.c_uint64(seed), C.c_uint32(stream), C.c_uint64(first),
                              C.c_uint64(count), C.c_uint32(q), _p(out))
@@ -59,6 +63,8 @@ def sample_uniform(seed, stream, first, count, q):
 
 
 def sample_noise(seed, stream, first, count, q, W):
+    if isinstance(seed, tuple):          # (key32, nonce): the keyed generator
+        return sample_noise_keyed(seed[0], seed[1], stream, first, count, q, W)
     out = np.empty(count, np.uint32)
     lib().qfo_sample_noise(C.c_uint64(seed), C.c_uint32(stream), C.c_uint64(first),
                            C.c_uint64(count), C.c_uint32(q), C.c_uint32(W), _p(out))
@@ -66,6 +72,8 @@ def sample_noise(seed, stream, first, count, q, W):
 
 
 def sample_discrete_gauss(seed, stream, first, count, q, n, s):
+    if isinstance(seed, tuple):          # (key32, nonce): the keyed generator
+        return sample_discrete_gauss_keyed(seed[0], seed[1], stream, first, count, q, n, s)
     out = np.empty(count, np.uint32)
     rc = lib().qfo_sample_discrete_gauss(C.c_uint64(seed), C.c_uint32(stream), C.c_uint64(first),
                                          C.c_uint64(count), C.c_uint32(q), C.c_uint32(n), C.c_double(s), _p(out))
@@ -75,9 +83,53 @@ def sample_discrete_gauss(seed, stream, first, count, q, n, s):
 
 
 def sample_bits(seed, stream, first_row, rows, cols, stride_bytes):
+    if isinstance(seed, tuple):          # (key32, nonce): the keyed generator
+        return sample_bits_keyed(seed[0], seed[1], stream, first_row, rows, cols, stride_bytes)
     out = np.empty((rows, stride_bytes), np.uint8)
     lib().qfo_sample_bits(C.c_uint64(seed), C.c_uint32(stream), C.c_uint64(first_row),
                           C.c_uint64(rows), C.c_uint32(cols), C.c_uint32(stride_bytes), _p(out))
+    return out
+
+
+# ---- the same samplers under a 256-bit key (ChaCha20 value function; include/qfgpu.h "*_keyed_dev")
+def chacha20_block(key32: bytes, counter: int, nonce: int):
+    out = np.empty(16, np.uint32)
+    lib().qfo_chacha20_block(C.c_char_p(bytes(key32)), C.c_uint64(counter), C.c_uint64(nonce), _p(out))
+    return out
+
+
+def rand64_keyed(key32: bytes, nonce, stream, idx):
+    return int(lib().qfo_rand64_keyed(bytes(key32), nonce, stream, idx))
+
+
+def sample_uniform_keyed(key32, nonce, stream, first, count, q):
+    out = np.empty(count, np.uint32)
+    lib().qfo_sample_uniform_keyed(C.c_char_p(bytes(key32)), C.c_uint64(nonce), C.c_uint32(stream), C.c_uint64(first),
+                                   C.c_uint64(count), C.c_uint32(q), _p(out))
+    return out
+
+
+def sample_noise_keyed(key32, nonce, stream, first, count, q, W):
+    out = np.empty(count, np.uint32)
+    lib().qfo_sample_noise_keyed(C.c_char_p(bytes(key32)), C.c_uint64(nonce), C.c_uint32(stream), C.c_uint64(first),
+                                 C.c_uint64(count), C.c_uint32(q), C.c_uint32(W), _p(out))
+    return out
+
+
+def sample_discrete_gauss_keyed(key32, nonce, stream, first, count, q, n, s):
+    out = np.empty(count, np.uint32)
+    rc = lib().qfo_sample_discrete_gauss_keyed(C.c_char_p(bytes(key32)), C.c_uint64(nonce), C.c_uint32(stream),
+                                               C.c_uint64(first), C.c_uint64(count), C.c_uint32(q), C.c_uint32(n),
+                                               C.c_double(s), _p(out))
+    if rc:
+        raise ValueError("discrete gauss: support s*log2(n) outside [1, 2^21]")
+    return out
+
+
+def sample_bits_keyed(key32, nonce, stream, first_row, rows, cols, stride_bytes):
+    out = np.empty((rows, stride_bytes), np.uint8)
+    lib().qfo_sample_bits_keyed(C.c_char_p(bytes(key32)), C.c_uint64(nonce), C.c_uint32(stream), C.c_uint64(first_row),
+                                C.c_uint64(rows), C.c_uint32(cols), C.c_uint32(stride_bytes), _p(out))
     return out
 
 

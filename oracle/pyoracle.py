@@ -43,6 +43,32 @@ def rand_below(seed, stream, idx, bound):
     return (rand64(seed, stream, idx) * bound) >> 64
 
 
+def chacha20_block(key32: bytes, counter: int, nonce: int):
+    """ChaCha20 block, 20 rounds, 64-bit counter in state words 12-13 and 64-bit nonce in 14-15 (the keyed
+    generator of include/qfgpu.h; same 16-word state as RFC 7539 2.3, whose test vector 2.3.2 pins it)."""
+    M = 0xFFFFFFFF
+    rot = lambda v, c: ((v << c) | (v >> (32 - c))) & M
+    st = [0x61707865, 0x3320646e, 0x79622d32, 0x6b206574]
+    st += [int.from_bytes(key32[4 * i:4 * i + 4], "little") for i in range(8)]
+    st += [counter & M, (counter >> 32) & M, nonce & M, (nonce >> 32) & M]
+    x = list(st)
+
+    def qr(a, b, c, d):
+        x[a] = (x[a] + x[b]) & M; x[d] = rot(x[d] ^ x[a], 16)
+        x[c] = (x[c] + x[d]) & M; x[b] = rot(x[b] ^ x[c], 12)
+        x[a] = (x[a] + x[b]) & M; x[d] = rot(x[d] ^ x[a], 8)
+        x[c] = (x[c] + x[d]) & M; x[b] = rot(x[b] ^ x[c], 7)
+    for _ in range(10):
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+    return [(a + b) & M for a, b in zip(x, st)]
+
+
+def rand64_keyed(key32: bytes, nonce: int, stream: int, idx: int) -> int:
+    o = chacha20_block(key32, idx, nonce ^ (stream << 48))
+    return o[0] | (o[1] << 32)
+
+
 def sample_uniform(seed, stream, first, count, q):
     return [rand_below(seed, stream, first + i, q) for i in range(count)]
 

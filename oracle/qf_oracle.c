@@ -110,8 +110,9 @@ void qfo_sample_noise(uint64_t seed, uint32_t stream, uint64_t first, uint64_t c
  * thr_i = floor(2^64 * P[X <= -T+i]).  Parity with the reference is distributional only (its
  * RNG is unseeded and qfall-math's sampler is not in /root/reference): "parity unpinned". */
 #include <math.h>
-int qfo_sample_discrete_gauss(uint64_t seed, uint32_t stream, uint64_t first, uint64_t count,
-                              uint32_t q, uint32_t n, double s, uint32_t *out) {
+uint64_t qfo_rand64_keyed(const uint8_t *key32, uint64_t nonce, uint32_t stream, uint64_t idx);
+static int gauss_impl(const uint8_t *key32, uint64_t seed, uint32_t stream, uint64_t first, uint64_t count,
+                      uint32_t q, uint32_t n, double s, uint32_t *out) {
     long double sl = (long double)s;
     long double Tl = ceill(sl * log2l((long double)n));
     if (!(Tl >= 1.0L) || Tl > 2097152.0L) return 1;
@@ -131,7 +132,7 @@ int qfo_sample_discrete_gauss(uint64_t seed, uint32_t stream, uint64_t first, ui
     }
     thr[len - 1] = UINT64_MAX;
     for (uint64_t i = 0; i < count; i++) {
-        uint64_t v = qfo_rand64(seed, stream, first + i);
+        uint64_t v = key32 ? qfo_rand64_keyed(key32, seed, stream, first + i) : qfo_rand64(seed, stream, first + i);
         size_t a = 0, b = len - 1;          /* smallest index whose threshold exceeds v */
         while (a < b) { size_t m = (a + b) / 2; if (thr[m] > v) b = m; else a = m + 1; }
         int64_t r = ((int64_t)a - T) % (int64_t)q;
@@ -140,6 +141,78 @@ int qfo_sample_discrete_gauss(uint64_t seed, uint32_t stream, uint64_t first, ui
     }
     free(cum); free(thr);
     return 0;
+}
+int qfo_sample_discrete_gauss(uint64_t seed, uint32_t stream, uint64_t first, uint64_t count,
+                              uint32_t q, uint32_t n, double s, uint32_t *out) {
+    return gauss_impl(NULL, seed, stream, first, count, q, n, s, out);
+}
+int qfo_sample_discrete_gauss_keyed(const uint8_t *key32, uint64_t nonce, uint32_t stream, uint64_t first, uint64_t count,
+                                    uint32_t q, uint32_t n, double s, uint32_t *out) {
+    return gauss_impl(key32, nonce, stream, first, count, q, n, s, out);
+}
+
+/* ---- keyed generator (include/qfgpu.h "*_keyed_dev"): ChaCha20, 20 rounds, 64-bit block counter
+ * (state words 12-13) and 64-bit nonce (words 14-15) -- D. J. Bernstein's original form.  RFC 7539
+ * 2.3 uses the same 16-word state with a 32-bit counter and a 96-bit nonce, so its block test vector
+ * (2.3.2) pins this function: words 12..15 = 1, 0x09000000, 0x4a000000, 0 are idx = 1 | 0x09000000<<32
+ * and nonce 0x4a000000 here (tests/test_oracle_golden.py).  value = output words 0,1 little-endian. */
+#define ROTL32(v, c) (((v) << (c)) | ((v) >> (32 - (c))))
+#define CHACHA_QR(a, b, c, d)                  \
+    a += b; d ^= a; d = ROTL32(d, 16);         \
+    c += d; b ^= c; b = ROTL32(b, 12);         \
+    a += b; d ^= a; d = ROTL32(d, 8);          \
+    c += d; b ^= c; b = ROTL32(b, 7);
+void qfo_chacha20_block(const uint8_t *key32, uint64_t counter, uint64_t nonce, uint32_t out16[16]) {
+    uint32_t in[16], x[16];
+    in[0] = 0x61707865u; in[1] = 0x3320646eu; in[2] = 0x79622d32u; in[3] = 0x6b206574u;
+    for (int i = 0; i < 8; i++)
+        in[4 + i] = (uint32_t)key32[4 * i] | ((uint32_t)key32[4 * i + 1] << 8) | ((uint32_t)key32[4 * i + 2] << 16) |
+                    ((uint32_t)key32[4 * i + 3] << 24);
+    in[12] = (uint32_t)counter; in[13] = (uint32_t)(counter >> 32);
+    in[14] = (uint32_t)nonce;   in[15] = (uint32_t)(nonce >> 32);
+    memcpy(x, in, sizeof x);
+    for (int r = 0; r < 10; r++) {
+        CHACHA_QR(x[0], x[4], x[8], x[12]) CHACHA_QR(x[1], x[5], x[9], x[13])
+        CHACHA_QR(x[2], x[6], x[10], x[14]) CHACHA_QR(x[3], x[7], x[11], x[15])
+        CHACHA_QR(x[0], x[5], x[10], x[15]) CHACHA_QR(x[1], x[6], x[11], x[12])
+        CHACHA_QR(x[2], x[7], x[8], x[13]) CHACHA_QR(x[3], x[4], x[9], x[14])
+    }
+    for (int i = 0; i < 16; i++) out16[i] = x[i] + in[i];
+}
+uint64_t qfo_rand64_keyed(const uint8_t *key32, uint64_t nonce, uint32_t stream, uint64_t idx) {
+    uint32_t o[16];
+    qfo_chacha20_block(key32, idx, nonce ^ ((uint64_t)stream << 48), o);
+    return (uint64_t)o[0] | ((uint64_t)o[1] << 32);
+}
+static inline uint32_t rand_below_keyed(const uint8_t *key32, uint64_t nonce, uint32_t stream, uint64_t idx, uint32_t bound) {
+    return (uint32_t)(((u128)qfo_rand64_keyed(key32, nonce, stream, idx) * bound) >> 64);
+}
+/* the samplers above with the keyed value function; everything after `value` is identical */
+void qfo_sample_uniform_keyed(const uint8_t *key32, uint64_t nonce, uint32_t stream, uint64_t first, uint64_t count,
+                              uint32_t q, uint32_t *out) {
+    for (uint64_t i = 0; i < count; i++) out[i] = rand_below_keyed(key32, nonce, stream, first + i, q);
+}
+void qfo_sample_bits_keyed(const uint8_t *key32, uint64_t nonce, uint32_t stream, uint64_t first_row, uint64_t rows,
+                           uint32_t cols, uint32_t stride_bytes, uint8_t *out) {
+    const uint64_t w64 = ((uint64_t)cols + 63) / 64;
+    memset(out, 0, (size_t)rows * stride_bytes);
+    for (uint64_t r = 0; r < rows; r++)
+        for (uint64_t w = 0; w < w64; w++) {
+            const uint64_t v = qfo_rand64_keyed(key32, nonce, stream, (first_row + r) * w64 + w);
+            for (uint32_t j = (uint32_t)(w * 64); j < cols && j < (w + 1) * 64; j++)
+                if ((v >> (j & 63)) & 1) out[r * stride_bytes + (j >> 3)] |= (uint8_t)(1u << (j & 7));
+        }
+}
+void qfo_sample_noise_keyed(const uint8_t *key32, uint64_t nonce, uint32_t stream, uint64_t first, uint64_t count,
+                            uint32_t q, uint32_t W, uint32_t *out) {
+    for (uint64_t i = 0; i < count; i++) {
+        int64_t v = 0;
+        for (int t = 0; t < 4; t++)
+            v += (int64_t)rand_below_keyed(key32, nonce, stream, (first + i) * 4 + t, 2 * W + 1) - (int64_t)W;
+        int64_t r = v % (int64_t)q;
+        if (r < 0) r += q;
+        out[i] = (uint32_t)r;
+    }
 }
 
 /* ------------------------------------------------ Z_q matrix products (kernels a, c) */

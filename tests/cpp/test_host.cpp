@@ -18,6 +18,9 @@ void qfo_sample_bits(uint64_t seed, uint32_t stream, uint64_t first_row, uint64_
 void qfo_sample_noise(uint64_t seed, uint32_t stream, uint64_t first, uint64_t count, uint32_t q, uint32_t W, uint32_t *out);
 void qfo_sample_uniform(uint64_t seed, uint32_t stream, uint64_t first, uint64_t count, uint32_t q, uint32_t *out);
 int qfo_sample_discrete_gauss(uint64_t seed, uint32_t stream, uint64_t first, uint64_t count, uint32_t q, uint32_t n, double s, uint32_t *out);
+int qfo_sample_discrete_gauss_keyed(const uint8_t *key32, uint64_t nonce, uint32_t stream, uint64_t first, uint64_t count, uint32_t q, uint32_t n,
+                                    double s, uint32_t *out);
+void qfo_sample_uniform_keyed(const uint8_t *key32, uint64_t nonce, uint32_t stream, uint64_t first, uint64_t count, uint32_t q, uint32_t *out);
 void qfo_polymul_negacyclic(const uint32_t *a, const uint32_t *b, uint32_t n, uint32_t q, uint32_t *c);
 void qfo_ringlpr_enc_batch(const uint32_t *a, const uint32_t *bpoly, uint32_t n, uint32_t q, const uint32_t *r, const uint32_t *e1,
                            const uint32_t *e2, const uint8_t *mu_bits, uint64_t B, uint32_t *u, uint32_t *v);
@@ -260,9 +263,12 @@ int main() {
             const uint64_t pos = r.randomness().take(3, 0);
             DevBuf<uint32_t> C = r.enc_batch(pk, msg);
             CHECK(r.dec_batch(sk, C.get(), msg.size()) == msg);
-            // the batch against the oracle on the same seeded SampleD draws
+            // the batch against the oracle on the same SampleD draws (a default-constructed object draws
+            // from ChaCha20 under its own fresh key: the oracle restates that generator too)
             std::vector<uint32_t> E(msg.size() * r.pp.m), K((size_t)(r.pp.n + 1) * r.pp.m), ref(msg.size() * (r.pp.n + 1));
-            CHECK(qfo_sample_discrete_gauss(r.randomness().seed(), 3, pos, E.size(), r.pp.q, r.pp.n, r.pp.r, E.data()) == 0);
+            const Seed &sd = r.randomness().seed();
+            CHECK(sd.keyed);
+            CHECK(qfo_sample_discrete_gauss_keyed(sd.key, sd.seed, 3, pos, E.size(), r.pp.q, r.pp.n, r.pp.r, E.data()) == 0);
             std::copy(pk.a.e.begin(), pk.a.e.end(), K.begin());
             std::copy(pk.v.e.begin(), pk.v.e.end(), K.begin() + (size_t)r.pp.n * r.pp.m);
             qfo_matmul_batch(K.data(), r.pp.n + 1, r.pp.m, r.pp.q, E.data(), 1, (size_t)r.pp.m * 4, msg.size(), nullptr, msg.data(), ref.data());
@@ -362,9 +368,15 @@ int main() {
     });
     run("default_seeds_are_fresh", [&] {  // two default-constructed schemes must not share secrets (advisor finding)
         Regev a = Regev::default_(dev), b = Regev::default_(dev);
-        CHECK(a.randomness().seed() != b.randomness().seed());
+        CHECK(a.randomness().seed().keyed && b.randomness().seed().keyed);   // ChaCha20 under 256 OS bits, not SplitMix64
+        CHECK(std::memcmp(a.randomness().seed().key, b.randomness().seed().key, 32) != 0);
         auto ka = a.gen(), kb = b.gen();
         CHECK(ka.second.e != kb.second.e);
+        // the public matrix of a default-constructed scheme IS the keyed stream 1 (and nothing SplitMix64 could produce)
+        const Seed &sa = a.randomness().seed();
+        std::vector<uint32_t> A0((size_t)a.n * a.m);
+        qfo_sample_uniform_keyed(sa.key, sa.seed, 1, 0, A0.size(), a.q, A0.data());
+        CHECK(std::equal(A0.begin(), A0.end(), ka.first.e.begin()));
         Regev c(dev, 13, 154, 1427, 0.01, 42), d(dev, 13, 154, 1427, 0.01, 42);   // explicit seed: reproducible
         CHECK(c.gen().second.e == d.gen().second.e);
     });

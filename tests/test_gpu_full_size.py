@@ -184,3 +184,68 @@ def test_ring_config5(ctx):
     rows = _rows(B, 4)
     t_ref, _ = co.fdh_ring_verify_batch(ctx.to_host_u32(A), q, s1[rows].cpu().numpy(), np.zeros((len(rows), n), np.uint32), big)
     assert np.array_equal(ctx.to_host_u32(t1[rows]), t_ref)
+
+
+@pytest.mark.timeout(300)
+def test_dual_regev_secure128(ctx):
+    """DualRegev at the reference's `secure128` shape (dual_regev.rs:301-303: n = 230, m = 5313, q = 7,764,299,
+    alpha = 0.0011), 8,192 messages.  The batched shape is the opposite of every other config: the key is the
+    transposed pk, (m+1) = 5,314 rows x n = 230 columns, the batch operand s is uniform in Z_q (3 digits) --
+    167 row blocks over two k-tiles.  enc (dual_regev.rs:403-410) against the oracle on sampled rows, the full
+    round trip through dec (dual_regev.rs:437-450: c^t * [-x ; 1]) with the reference's own noise width
+    (W = round(alpha*q/sqrt(2 pi) * sqrt(3)/2) = 2951: decryption noise sigma 1.8e5 against q/4 = 1.9e6), and
+    linearity of the product in s."""
+    n, m, q, B, W = 230, 5313, 7764299, 8192, 2951
+    A = ctx.sample_uniform(SEED, 1, 0, n * m, q).view(n, m)
+    xb = ctx.sample_bits(SEED, 2, 0, 1, m)                                   # sk = x in {0,1}^m
+    x_h = np.unpackbits(ctx.to_host_u8(xb), axis=1, bitorder="little")[0, :m].astype(np.uint32)
+    ka = ctx.key_upload(A, q)
+    u = ctx.matvec(ka, x_h)                                                 # u = A x (dual_regev.rs:354)
+    assert np.array_equal(u, co.matvec(ctx.to_host_u32(A), x_h, q))
+    pk_h = np.hstack([ctx.to_host_u32(A), u[:, None]])                      # n x (m+1)
+    key = ctx.key_upload(pk_h, q, transpose=True)
+    assert (key.rows, key.cols) == (m + 1, n)
+    s = ctx.sample_uniform(SEED, 3, 0, B * n, q).view(B, n)
+    e = ctx.sample_noise(SEED, 4, 0, B * (m + 1), q, W).view(B, m + 1)
+    msg = (ctx.sample_uniform(SEED, 5, 0, B, 2) & 1).to(torch.uint8)
+    c = ctx.matmul(key, s, X_U32, B, addend=e, msg=msg)
+    w = ctx.to_dev_u32((q - x_h.astype(np.int64)) % q)                      # [-x ; 1]
+    assert torch.equal(ctx.dot_decode(w, q, c), msg)                        # round trip of every message
+    rows = _rows(B, 40)
+    pkT = np.ascontiguousarray(pk_h.T)
+    ref = co.matmul_batch(pkT, q, ctx.to_host_u32(s[rows]), co.X_U32, len(rows), addend=ctx.to_host_u32(e[rows]),
+                          msg=ctx.to_host_u8(msg[rows]), mt=True)
+    assert np.array_equal(ctx.to_host_u32(c[rows]), ref)
+    assert np.array_equal(ctx.to_host_u8(ctx.dot_decode(w, q, c[rows].contiguous())),
+                          co.dualregev_decode_batch(x_h.astype(np.int32), q, ref))
+    # linear in s, no addend: pk^t (s1 + s2) = pk^t s1 + pk^t s2
+    s2 = ctx.sample_uniform(SEED, 3, B * n, B * n, q).view(B, n)
+    ss = ((_i64(s) + _i64(s2)) % q).to(torch.int32)
+    h1, h2, hs = (ctx.matmul(key, v, X_U32, B) for v in (s, s2, ss))
+    assert torch.equal((_i64(h1) + _i64(h2)) % q, _i64(hs))
+    # a batch that ends inside a message tile (B mod 256 = 93, mod 32 = 29) at the full K: rows of the last tile
+    Bp = 4096 + 93
+    cp = ctx.matmul(key, s[:Bp], X_U32, Bp, addend=e[:Bp], msg=msg[:Bp])
+    assert torch.equal(cp, c[:Bp])
+
+
+@pytest.mark.parametrize("n,q", [(256, 1073479681), (1024, 1073479681), (256, 92897729), (1024, 16777213)])
+def test_ring_product_by_kernel_a(ctx, n, q):
+    """Kernel (b) cross-checked by kernel (a) on the device, no oracle in between (SURVEY 7 "an independent GPU
+    cross-check"): Rot^-(a) * b = a * b in Z_q[X]/(X^n+1) (utils/rotation_matrix.rs:45-67).  The rotation matrix
+    is built on the host (column j = coefficients of a * X^j), uploaded as a Z_q key, and the batch of b's goes
+    through the int8-MFMA product; the same batch through qf_polymul_dev with a repeated.  NTT-friendly q (wave
+    NTT kernel) and q with 2n not dividing q-1 (exact schoolbook kernel)."""
+    from crypto_amd.utils.rotation_matrix import rot_minus
+    B = 512
+    a = ctx.sample_uniform(SEED, 6, 0, n, q)
+    b = ctx.sample_uniform(SEED, 6, n, B * n, q).view(B, n)
+    a_h = ctx.to_host_u32(a).astype(np.int64)
+    rot = np.mod(rot_minus(a_h).astype(np.int64), q).astype(np.uint32)     # n x n, column j = a * X^j
+    assert rot[0, 1] == (q - a_h[n - 1]) % q and rot[1, 0] == a_h[1]
+    key = ctx.key_upload(rot, q)
+    by_a = ctx.matmul(key, b, X_U32, B)
+    ring = ctx.ring(n, q)
+    assert ring.uses_ntt == ((q - 1) % (2 * n) == 0)
+    by_b = ring.polymul(a[None].expand(B, n).contiguous(), b)
+    assert torch.equal(by_a, by_b)

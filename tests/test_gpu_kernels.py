@@ -460,6 +460,31 @@ def test_discrete_gauss_sampler(ctx, q, n, s):
     assert chi2 < keep.sum() + 6 * np.sqrt(2 * keep.sum()), (chi2, keep.sum())
 
 
+def test_keyed_samplers_match_the_oracle(ctx):
+    """qf_sample_*_keyed_dev (ChaCha20 under a 256-bit key: what an object constructed without a seed draws
+    from) against the oracle's restatement, which RFC 7539's block vector pins (tests/test_oracle_golden.py):
+    uniform, bit rows (16-byte and 4-byte stride paths), Irwin-Hall noise, D_{Z,s}; counters beyond 2^32."""
+    key = bytes((11 * i + 5) & 255 for i in range(32))
+    sd = (key, 0x0123456789ABCDEF)
+    q = 1073741789
+    for first in (0, 77, (1 << 33) + 5):
+        assert np.array_equal(ctx.to_host_u32(ctx.sample_uniform(sd, 1, first, 5000, q)),
+                              co.sample_uniform_keyed(key, sd[1], 1, first, 5000, q))
+    assert np.array_equal(ctx.to_host_u32(ctx.sample_noise(sd, 4, 9, 3000, q, 3333)), co.sample_noise_keyed(key, sd[1], 4, 9, 3000, q, 3333))
+    assert np.array_equal(ctx.to_host_u32(ctx.sample_discrete_gauss(sd, 2, 5, 4000, 983, 10, 7.08)),
+                          co.sample_discrete_gauss_keyed(key, sd[1], 2, 5, 4000, 983, 10, 7.08))
+    for cols, stride in ((867, None), (6168, None), (77, 12), (64, 8)):
+        st = stride or bit_stride(cols)
+        assert np.array_equal(ctx.to_host_u8(ctx.sample_bits(sd, 3, 3, 9, cols, stride=st)), co.sample_bits_keyed(key, sd[1], 3, 3, 9, cols, st))
+    # another key, another nonce, another stream: different draws
+    a = ctx.to_host_u32(ctx.sample_uniform(sd, 1, 0, 64, q))
+    assert not np.array_equal(a, ctx.to_host_u32(ctx.sample_uniform((bytes(32), sd[1]), 1, 0, 64, q)))
+    assert not np.array_equal(a, ctx.to_host_u32(ctx.sample_uniform((key, sd[1] + 1), 1, 0, 64, q)))
+    assert not np.array_equal(a, ctx.to_host_u32(ctx.sample_uniform(sd, 2, 0, 64, q)))
+    with pytest.raises(QfError):
+        ctx.sample_uniform((b"short", 0), 1, 0, 4, q)
+
+
 def test_replay_fixtures_on_device(ctx):
     """The fixtures meant for replay through the real reference (tests/golden/replay):
     the device reproduces every expected value."""

@@ -93,6 +93,39 @@ def test_generator_c_vs_python():
     assert not np.unpackbits(bits, axis=1, bitorder="little")[:, 77:].any()
 
 
+def test_keyed_generator_chacha20():
+    """The keyed generator (qf_sample_*_keyed_dev: what an object constructed without a seed draws from) is
+    ChaCha20 in counter mode.  Pinned by the block test vector of RFC 7539 section 2.3.2 (key 00..1f, counter 1,
+    nonce 00:00:00:09:00:00:00:4a:00:00:00:00 = state words 12..15 = 1, 0x09000000, 0x4a000000, 0), in the C
+    oracle and in the independent Python restatement; then the keyed samplers C vs Python."""
+    key = bytes(range(32))
+    want = [0xe4e7f110, 0x15593bd1, 0x1fdd0f50, 0xc47120a3, 0xc7f4d1c7, 0x0368c033, 0x9aaa2204, 0x4e6cd4c3,
+            0x466482d2, 0x09aa9f07, 0x05d7c214, 0xa2028bd9, 0xd19c12b5, 0xb94e16de, 0xe883d0cb, 0x4e3c50a2]
+    ctr, nonce = 1 | (0x09000000 << 32), 0x4a000000
+    assert co.chacha20_block(key, ctr, nonce).tolist() == want
+    assert po.chacha20_block(key, ctr, nonce) == want
+    k2 = bytes((7 * i + 3) & 255 for i in range(32))
+    for stream, idx in ((1, 0), (2, 5), (4, (1 << 40) + 9)):
+        assert co.rand64_keyed(k2, 0x1234, stream, idx) == po.rand64_keyed(k2, 0x1234, stream, idx)
+    q = 1073741789
+    v = [po.rand64_keyed(k2, 9, 1, 3 + i) for i in range(50)]
+    assert co.sample_uniform_keyed(k2, 9, 1, 3, 50, q).tolist() == [(x * q) >> 64 for x in v]
+    W = 300
+    nz = co.sample_noise_keyed(k2, 9, 4, 2, 10, q, W).tolist()
+    for i in range(10):
+        t = sum(((po.rand64_keyed(k2, 9, 4, (2 + i) * 4 + j) * (2 * W + 1)) >> 64) - W for j in range(4))
+        assert nz[i] == t % q
+    bits = np.unpackbits(co.sample_bits_keyed(k2, 9, 3, 2, 3, 77, 16), axis=1, bitorder="little")
+    for r in range(3):
+        for j in range(77):
+            assert bits[r, j] == (po.rand64_keyed(k2, 9, 3, (2 + r) * 2 + (j >> 6)) >> (j & 63)) & 1
+    assert not bits[:, 77:].any()
+    # the keyed and the seeded Gaussian share the inversion table: equal draws give equal samples
+    g = co.sample_discrete_gauss_keyed(k2, 9, 4, 0, 2000, 983, 10, 7.0).astype(np.int64)
+    g[g > 491] -= 983
+    assert np.abs(g).max() <= 24 and abs(g.mean()) < 0.5 and abs(g.var() / (49 / (2 * np.pi)) - 1) < 0.15
+
+
 @pytest.mark.parametrize("case", VEC["regev"])
 def test_regev_vectors(case):
     n, m, q, B = case["n"], case["m"], case["q"], case["B"]
