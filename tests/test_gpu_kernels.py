@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import coracle as co
-from crypto_amd.device import X_BITS, X_I32, X_U32, bit_stride, pack_bits
+from crypto_amd.device import QfError, X_BITS, X_I32, X_U32, bit_stride, pack_bits
 
 pytestmark = pytest.mark.gpu
 SEED = 0x5146414C4C
