@@ -2,7 +2,15 @@
 """Benchmarks of the hot path through the C ABI on MI355X.  Headline (BASELINE.json config 2):
 batched Regev enc+dec, n=256, m=6168, q=16,777,213, 65,536 one-bit messages per GPU.
 
-  python bench.py --gpus N --steps K --warmup W [--workload regev|sis|lpr|ringlpr|fdh|matvec|regev_cycle]
+  python bench.py --gpus N --steps K --warmup W [--workload regev|sis|lpr|ringlpr|fdh|matvec|dualregev|regev_cycle]
+
+With no --workload the ONE JSON line is the headline, and -- after the headline's own timed region,
+in the same process -- every other configuration is run at BASELINE's size on the same clock and
+appended as a sub-object of that line (`sis`, `lpr`, `ringlpr`, `fdh_verify`, `matvec`, `dual_regev`;
+`ring_polymul` as before), each with its `value`, `ms_per_step`, `roofline` and a bounded
+`cpu_baseline`.  The headline keys do not move.  --headline-only skips them; --workload X prints that
+configuration's object as a line of its own (what the per-workload rocprofv3 passes under
+profiles/r3/<X>/ run).
 
 N > 1: when WORLD_SIZE is not set this process only LAUNCHES N fresh rank processes (one per GPU,
 RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their environment, rendezvous on 127.0.0.1) before anything
@@ -37,10 +45,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SEED = 0x5146414C4C
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r2")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r3")
 INT8_PEAK_TOPS = 5033.0   # 2048 int8 op/clk/SIMD x 1024 SIMDs x 2.4 GHz (MI355X_MICROARCH.md "Matrix cores": I8 = 2x BF16)
 HBM_PEAK_GBS = 8000.0
-WORKLOADS = ["regev", "sis", "lpr", "ringlpr", "fdh", "matvec", "regev_cycle"]
+WORKLOADS = ["regev", "sis", "lpr", "ringlpr", "fdh", "matvec", "dualregev", "regev_cycle"]
+SUBS = [("sis", "sis"), ("lpr", "lpr"), ("ringlpr", "ringlpr"), ("fdh", "fdh_verify"), ("matvec", "matvec"), ("dualregev", "dual_regev")]
 
 
 def parse():
@@ -59,6 +68,9 @@ def parse():
     ap.add_argument("--no-check", action="store_true", help="skip the small property-check launches (profile runs: keeps "
                                                              "the kernel-trace averages to full-size launches only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--headline-only", action="store_true", help="do not append the other configurations to the headline line")
+    ap.add_argument("--sub-steps", type=int, default=20, help="timed steps of each appended configuration (their steps take 1.6-3 ms)")
+    ap.add_argument("--sub-cpu-seconds", type=float, default=4.0, help="CPU baseline budget of each appended configuration")
     ap.add_argument("--workload", default="regev", choices=WORKLOADS,
                     help="regev = the headline (BASELINE config 2); the others are the remaining configs, "
                          "each printing its own JSON line")
@@ -82,26 +94,42 @@ def launch_ranks(args) -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    import tempfile
+    out0 = tempfile.TemporaryFile()
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), QF_BENCH_LAUNCHED="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    rc = procs[0].returncode
-    deadline = time.time() + 120
-    for p in procs[1:]:
-        try:
-            p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    # Watchdog: the ranks meet in collectives, so ONE rank that dies (before the rendezvous or later) would
+    # leave the others waiting for the process group's timeout.  Poll all of them; the first non-zero exit
+    # ends the run: the siblings (fresh children of this process, never an exec) are killed and that status
+    # is returned, also when rank 0 itself had finished cleanly.  Ranks still running 120 s after the first
+    # clean exit are taken to be stuck.
+    rc, first_done = 0, None
+    while True:
+        states = [p.poll() for p in procs]
+        bad = [st for st in states if st not in (None, 0)]
+        if bad:
+            rc = bad[0]
+            break
+        if all(st == 0 for st in states):
+            break
+        if first_done is None and any(st == 0 for st in states):
+            first_done = time.time()
+        if first_done is not None and time.time() - first_done > 120:
+            sys.stderr.write("bench.py: a rank is still running 120 s after another finished; killing the run\n")
+            rc = 1
+            break
+        time.sleep(0.1)
+    for p in procs:
+        if p.poll() is None:
             p.kill()
-        rc = rc or p.returncode or 0
-    if rc != 0:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
-    sys.stdout.write(out0)
+    for p in procs:
+        p.wait()
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
     return rc
 
@@ -141,6 +169,7 @@ class Run:
         self.local = local
         self.dist = None
         self.backend = None
+        self.rank_ms = None
         if self.world > 1:
             import torch.distributed as dist
             self.dist = dist
@@ -233,7 +262,10 @@ class Run:
         torch.cuda.synchronize()
         self.barrier()
         el = time.perf_counter() - t0
-        return self.max_over_ranks(el), e0.elapsed_time(e1)
+        ems = e0.elapsed_time(e1)
+        # every rank's own reading of the region (HIP events on its launch stream): min and max over ranks show stragglers
+        self.rank_ms = (-self.max_over_ranks(-ems / steps), self.max_over_ranks(ems / steps)) if self.world > 1 else None
+        return self.max_over_ranks(el), ems
 
     def sampled_ms(self, parts, steps, every=4):
         """Untimed second pass of the SAME step loop (all parts of a step, in order, `steps` times -- the clock
@@ -344,6 +376,7 @@ def headline(args):
     for i in range(NS):
         enc(i)
     elapsed, region_ms = R_.timed(step, args.steps, args.warmup)
+    hl_rank_ms = R_.rank_ms
     check_round_trip()
     value = world * B * args.steps / elapsed
 
@@ -440,6 +473,21 @@ def headline(args):
                                          "GPU ciphertexts of the sample verified bit-identical"}
     elif rank == 0:
         out["cpu_baseline"] = None
+    if R_.rank_ms is not None:
+        out["ms_per_step_ranks"] = {"min": hl_rank_ms[0], "max": hl_rank_ms[1]}
+
+    # ---- every other configuration on the same clock, as sub-objects of this line -------------
+    if not args.headline_only:
+        import types
+        sets.clear()
+        sub = types.SimpleNamespace(**vars(args))
+        sub.steps, sub.warmup, sub.cpu_seconds = max(3, min(args.steps, args.sub_steps)), min(args.warmup, 3), args.sub_cpu_seconds
+        for wl, name in SUBS:
+            torch.cuda.empty_cache()
+            t1 = time.perf_counter()
+            o = workload(R_, wl, sub)
+            o["wall_s"] = time.perf_counter() - t1
+            out[name] = o
     R_.emit(out)
 
 
@@ -451,13 +499,20 @@ def bit_stride_bytes(cols):
 # the other configs
 # ---------------------------------------------------------------------------------------------
 def other_workloads(args):
-    """Configs 1, 3, 4, 5 of BASELINE.json and the single-message mat-vec: same conventions, one JSON line each."""
-    import numpy as np
+    """--workload X: that configuration's object as the one JSON line."""
     R_ = Run(args)
+    out = workload(R_, args.workload, args)
+    out.update(R_.meta())
+    R_.emit(out)
+
+
+def workload(R_, wl, args):
+    """Configs 1, 3, 4, 5 of BASELINE.json, the single-message mat-vec and DualRegev at secure128: same conventions
+    as the headline; returns the object (a line of its own under --workload, a sub-object of the headline line otherwise)."""
+    import numpy as np
     torch, ctx, rank, world = R_.torch, R_.ctx, R_.rank, R_.world
     from crypto_amd.device import X_BITS, X_U32
     from crypto_amd import sharding
-    wl = args.workload
     want_cpu = rank == 0 and world == 1 and not args.no_cpu
     co = None
     if want_cpu or wl == "regev_cycle":
@@ -717,6 +772,85 @@ def other_workloads(args):
                     "roofline": {"kernel": kname, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(wl, kpre) if world == 1 else None,
                                  "launch_ms": ms, "note": f"algorithmic bytes = {bytes_per} per unit x {B} per launch; one launch per step, exact Z_q (Shoup NTT)"}})
+    elif wl == "dualregev":
+        # DualRegev at the reference's secure128 set (dual_regev.rs:301-303): the batched shape is the opposite of every
+        # other config -- the key is the transposed pk, (m+1) x n = 5,314 x 230, the batch operand s is uniform in Z_q
+        # (3 digits), and every encryption reads m+1 noise words and writes m+1 ciphertext words: 43 KB of HBM traffic
+        # against 2.2e7 int8 ops (507 op/B, below the chip's 629 op/B balance) -- nominally HBM-bound.
+        n, m, q, W = 230, 5313, 7764299, 2951
+        Btot = 1 << 16
+        lo, hi = sharding.shard_range(Btot, rank, world)
+        B = hi - lo
+        pk = ctx.empty_u32(n, m + 1)
+        xsk = ctx.sample_bits(SEED, 2, 0, 1, m)
+        if rank == 0:                                                           # gen: u = A x (dual_regev.rs:354)
+            A = ctx.sample_uniform(SEED, 1, 0, n * m, q).view(n, m)
+            x_h = np.unpackbits(ctx.to_host_u8(xsk), axis=1, bitorder="little")[0, :m].astype(np.uint32)
+            pk[:, :m] = A
+            pk[:, m] = ctx.to_dev_u32(ctx.matvec(ctx.key_upload(A, q), x_h))
+        bcast["s"] += R_.broadcast(pk)
+        key = ctx.key_upload(pk, q, transpose=True)                             # rows m+1, cols n
+        sv = ctx.sample_uniform(SEED, 3, lo * n, B * n, q).view(B, n)
+        e = ctx.sample_noise(SEED, 4, lo * (m + 1), B * (m + 1), q, W).view(B, m + 1)
+        msg = (ctx.sample_uniform(SEED, 5, lo, B, 2) & 1).to(torch.uint8)
+        c = ctx.empty_u32(B, m + 1)
+        ctx.set_timing(False)
+        el, ems = R_.timed(lambda: ctx.matmul(key, sv, X_U32, B, addend=e, msg=msg, out=c), args.steps, args.warmup)
+        ms = ems / args.steps
+        gms = []
+        ctx.set_timing(True)
+        for _ in range(max(3, min(args.steps, 20))):
+            ctx.matmul(key, sv, X_U32, B, addend=e, msg=msg, out=c)
+            gms.append(ctx.last_kernel_ms("gemm"))
+        ctx.set_timing(False)
+        gemm_ms = float(np.mean(gms))
+        ops = 2 * 3 * 3 * (m + 1) * n
+        bytes_per = 4 * n + 8 * (m + 1)
+        tops = ops * B / (gemm_ms * 1e-3) / 1e12
+        gbs = bytes_per * B / (gemm_ms * 1e-3) / 1e9
+        out.update({"metric": "DualRegev encryptions/sec (secure128)", "value": Btot * args.steps / el, "unit": "encryptions/s", "scaling": "strong",
+                    "ms_per_step": el / args.steps * 1e3, "dtype": "int8",
+                    "config": {"workload": "DualRegev enc, secure128 (dual_regev.rs:301-303): c^t = s^t [A|u] + e^t, s uniform in Z_q (3 digits)",
+                               "n": n, "m": m, "q": q, "global_batch": Btot, "key_broadcast_ms": bcast["s"] * 1e3},
+                    "roofline": {"kernel": "qf_gemm_kernel<3,3,...> (3x3 digit products, K = n = 230: two k-tiles)", "bound": "hbm",
+                                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                 "traffic": pmc_traffic("dualregev", "qf_gemm_kernel") if world == 1 else None, "launch_ms": gemm_ms,
+                                 "whole_call_ms": ms, "mfma_tops": tops, "mfma_frac": tops / INT8_PEAK_TOPS,
+                                 "note": "algorithmic bytes = 4n (s) + 4(m+1) (e) + 4(m+1) (c) = 43,432 per encryption; algorithmic int8 ops = "
+                                         "2*3*3*(m+1)*n = 21,999,960 per encryption: 507 op/B, below the 629 op/B balance of the chip"}})
+        # decryption (dual_regev.rs:437-450): c^t [-x ; 1] and the decision rule -- 21 KB per ciphertext, HBM-cold by size
+        w_dec = ((q - (ctx.to_dev_u32(np.unpackbits(ctx.to_host_u8(xsk), axis=1, bitorder="little")[0, :m].astype(np.uint32)).to(torch.int64))) % q).to(torch.int32)
+        bits_dec = ctx.empty_u8(B)
+        for _ in range(3):
+            ctx.dot_decode(w_dec, q, c, out=bits_dec)
+        assert torch.equal(bits_dec, msg), "DualRegev round trip failed"
+        ctx.set_timing(True)
+        dms = []
+        for _ in range(max(3, min(args.steps, 20))):
+            ctx.dot_decode(w_dec, q, c, out=bits_dec)
+            dms.append(ctx.last_kernel_ms("decode"))
+        ctx.set_timing(False)
+        dec_ms = float(np.mean(dms))
+        dec_gbs = B * 4 * (m + 1) / (dec_ms * 1e-3) / 1e9
+        out["decode"] = {"kernel": "qf_dot_decode_kernel", "bound": "hbm", "launch_ms": dec_ms, "achieved": dec_gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": dec_gbs / HBM_PEAK_GBS, "decryptions_per_s": B * world / (dec_ms * 1e-3),
+                         "note": "algorithmic bytes = 4(m+1) per ciphertext; every one of the batch decrypts to its message"}
+        if want_cpu:
+            pkT = np.ascontiguousarray(ctx.to_host_u32(pk).T)
+            threads = co.num_threads()
+            probe = 8
+            t1 = time.perf_counter()
+            co.matmul_batch(pkT, q, ctx.to_host_u32(sv[:probe]), co.X_U32, probe, addend=ctx.to_host_u32(e[:probe]), msg=ctx.to_host_u8(msg[:probe]))
+            per1 = (time.perf_counter() - t1) / probe
+            sample = cpu_sample_size(threads, per1, args.cpu_seconds, B)
+            s_h, e_h, m_h = ctx.to_host_u32(sv[:sample]), ctx.to_host_u32(e[:sample]), ctx.to_host_u8(msg[:sample])
+            t1 = time.perf_counter()
+            c_h = co.matmul_batch(pkT, q, s_h, co.X_U32, sample, addend=e_h, msg=m_h, mt=True)
+            cpu_t = time.perf_counter() - t1
+            assert np.array_equal(c_h, ctx.to_host_u32(c[:sample])), "GPU ciphertexts differ from the CPU oracle"
+            out["cpu_baseline"] = {"value": sample / cpu_t, "unit": "encryptions/s", "cores": threads, "kind": "port",
+                                   "sample": f"{sample} of the {B} messages (s^t*pk + e^t + msg per call, OpenMP over messages); single-thread "
+                                             f"{1.0 / per1:.1f}/s on a {probe}-message probe; GPU ciphertexts of the sample verified bit-identical"}
     elif wl == "regev_cycle":
         # BASELINE config 1 = the reference's own criterion bench (benches/regev.rs:15-57): one
         # gen + enc + dec cycle of ONE bit at new_from_n(n), n = 50 and the sweep 10..60.  The CPU
@@ -796,8 +930,9 @@ def other_workloads(args):
             out["cpu_baseline"] = {"value": reps / cpu_t, "unit": "hashes/s", "cores": 1, "kind": "port",
                                    "sample": f"{reps} single-message hashes of one key (one mat-vec per call, the reference is single-threaded; "
                                              "key warm in the CPU caches); GPU digest verified bit-identical"}
-    out.update(R_.meta())
-    R_.emit(out)
+    if R_.rank_ms is not None:
+        out["ms_per_step_ranks"] = {"min": R_.rank_ms[0], "max": R_.rank_ms[1]}
+    return out
 
 
 if __name__ == "__main__":

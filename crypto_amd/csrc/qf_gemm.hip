@@ -29,6 +29,12 @@
 #include "qf_internal.h"
 
 #define QF_NW 8          // waves per workgroup
+#ifndef QF_EPI_AUX_LD
+#define QF_EPI_AUX_LD 0  // cache policy of the epilogue's addend loads (2 = nt)
+#endif
+#ifndef QF_EPI_AUX_ST
+#define QF_EPI_AUX_ST 0  // cache policy of the epilogue's output stores (2 = nt)
+#endif
 #define QF_KS 4          // k-steps (of 32) per k-tile -> BK = 128
 
 // ---------------------------------------------------------------------------------------------
@@ -717,7 +723,7 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a, const uint32_t
                 if (a.addend) {          // 16 loads in flight
 #pragma unroll
                     for (int r = 0; r < 16; r++)
-                        add[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_add, (int)(voff_st + ((r & 3) + 8 * (r >> 2)) * rowbytes), 0, 0);
+                        add[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_add, (int)(voff_st + ((r & 3) + 8 * (r >> 2)) * rowbytes), 0, QF_EPI_AUX_LD);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; r++) add[r] = 0;
@@ -753,7 +759,7 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a, const uint32_t
                     }
                 __builtin_amdgcn_raw_buffer_store_b32(
                     (int)qf_epi_f64<S>(acc[i][j][0][r], acc[i][j][S > 1 ? 1 : 0][r], acc[i][j][S > 2 ? 2 : 0][r], acc[i][j][S > 3 ? 3 : 0][r], extra, a),
-                    rs_out, voff, 0, 0);
+                    rs_out, voff, 0, QF_EPI_AUX_ST);
             }
 #ifdef QF_STAMP
             QF_T(te2)
@@ -1150,6 +1156,226 @@ __global__ __launch_bounds__(QF_NW * 64, 2) void qf_gemm_packedx_kernel(QfGemmAr
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// Short inner dimension, many key rows (round 3): DualRegev -- c^t = s^t [A|u] + e^t with the key
+// (m+1) x n = 5,314 x 230 at secure128 (dual_regev.rs:301-303,403), K' = 3 folded digits x 256 = 768.
+// In the tiled kernel above a workgroup of that shape runs 6 k-tiles and then an epilogue of the same
+// length, all 8 waves in step (they meet at a barrier every k-tile): the matrix pipe idles through
+// every epilogue, the memory pipe through every main loop (stamps: loop 0.55, epilogue 0.45 of a
+// wave's cycles; MFMA-busy 0.25; 1.33 ms for 65,536 encryptions).
+// Here the roles of the loops are swapped.  A workgroup takes ONE column tile (WN*32 key rows) and
+// keeps ALL its digit planes in LDS -- WN * K'/32 * LA KiB, loaded once (144 KiB for the shape
+// above) -- and its 8 waves then sweep over message blocks on their own: no barrier after the
+// prologue, so one wave's epilogue (addend loads, fp64 reduction, stores) runs beside the MFMAs of
+// the other wave of its SIMD.  The batch operand comes from global memory a group of 4 k-steps
+// ahead; the next block's first group and this block's addend words are requested before the
+// stores of the epilogue are issued (vmcnt retires in order: a load queued behind 32 stores could
+// not be consumed before they have all been acknowledged).
+// Work units (column tile c, message split p) are dealt to the XCDs in runs: unit u = c*P + p goes
+// to XCD u / upx, so the workgroups that share a stream of operand planes (same p, neighbouring c)
+// and the output lines that straddle two column tiles meet in ONE L2.
+template <int LA, int WN>
+__global__ __launch_bounds__(QF_NW * 64, 2) void qf_gemm_shortk_kernel(QfGemmArgs a, uint32_t P, uint32_t nunits, uint32_t upx) {
+    constexpr int S = LA;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // WN * ks * LA KiB
+    const int lane = (int)threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const uint32_t u = xcd * upx + slot;
+    if (slot >= upx || u >= nunits) return;                       // uniform: whole workgroup
+    const uint32_t c = u / P, p = u % P;
+    const uint32_t rb0 = c * WN;
+    const uint64_t nmb = (a.B + 31) / 32;
+    const uint64_t per = (nmb + P - 1) / P;
+    const uint64_t mb_begin = p * per, mb_end = mb_begin + per < nmb ? mb_begin + per : nmb;
+    const uint32_t fprb = a.ks * LA;                              // fragments (KiB) per row block
+
+    // ---- the column tile's planes -> LDS, image [j][k-step][digit][64 lanes][16 B] = the HBM order of a row block
+    for (uint32_t f = (uint32_t)wave; f < WN * fprb; f += QF_NW) {
+        const uint32_t j = f / fprb, rem = f % fprb;
+        uint32_t rbi = rb0 + j;
+        rbi = rbi < a.rb ? rbi : a.rb - 1;                        // padded column tile: harmless duplicate
+        const int8_t *g = a.kplanes + ((size_t)rbi * fprb + rem) * 1024 + (size_t)lane * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                         (__attribute__((address_space(3))) void *)(smem + (size_t)f * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (mb_begin + wave >= mb_end) return;
+
+    const uint32_t lastrow = a.rows - 1;
+    const uint32_t rowbytes = a.rows * 4;
+    const uint32_t he = (uint32_t)lane >> 5;
+    const uint32_t voff_st = 4 * he * rowbytes + ((uint32_t)lane & 31) * 4;   // byte offset of (message 4h, column lane & 31)
+    const uint32_t G = a.ks / QF_KS;                              // groups of 4 k-steps
+    const __attribute__((address_space(3))) uint8_t *ldsl = (const __attribute__((address_space(3))) uint8_t *)smem + lane * 16;
+    const bool tile_has_last = a.msg != nullptr && lastrow >= rb0 * 32 && lastrow < (rb0 + WN) * 32;
+
+    // Operand registers: av = the group of 4 k-steps being multiplied, avn = the next one (requested at the top
+    // of the current group: the last group of a block requests the first group of the wave's next block);
+    // bf = the key fragments of the current and the next k-step (LDS reads one k-step ahead, one read between
+    // consecutive MFMAs; the k-step behind a block's last one is k-step 0 again: the tile is the same for every
+    // block, so the read-ahead simply wraps around).
+#ifdef QF_ABL_SK_HOTX
+#define QFS_MB(m_) ((m_) & 7)      /* ablation: every wave re-reads the same 8 blocks of operand planes (L1/L2-hot) */
+#else
+#define QFS_MB(m_) (m_)
+#endif
+    constexpr int NBF = WN * LA;
+    constexpr bool PFB = NBF * 16 + 2 * NBF * 4 + 8 * QF_KS + WN * 16 <= 216;   // LA = 4: no registers for the second fragment set
+    v4i av[QF_KS], avn[QF_KS], bf[PFB ? 2 : 1][NBF];
+#define QFS_LOAD_GROUP(dst_, mb_, kg_)                                                             \
+    {                                                                                              \
+        const int8_t *x_ = a.xplanes + ((size_t)QFS_MB(mb_) * a.ks + (size_t)(kg_) * QF_KS) * 1024 + (size_t)lane * 16; \
+        _Pragma("unroll") for (int i_ = 0; i_ < QF_KS; i_++) dst_[i_] = *(const v4i *)(x_ + i_ * 1024); \
+    }
+#define QFS_LOAD_B(set_, k_)                                                                       \
+    _Pragma("unroll") for (int j_ = 0; j_ < WN; j_++)                                              \
+        _Pragma("unroll") for (int l_ = 0; l_ < LA; l_++)                                          \
+            bf[set_][j_ * LA + l_] = *(const __attribute__((address_space(3))) v4i *)(ldsl + ((size_t)j_ * fprb + (size_t)(k_) * LA + l_) * 1024);
+#define QFS_GROUP(kg_)                                                                             \
+    _Pragma("unroll") for (int i_ = 0; i_ < QF_KS; i_++) {                                         \
+        if constexpr (PFB) {                                                                       \
+            uint32_t kn_ = (kg_) * QF_KS + i_ + 1;                                                 \
+            kn_ = kn_ < a.ks ? kn_ : 0;                                                            \
+            QFS_LOAD_B((i_ + 1) & 1, kn_)                                                          \
+        } else {                                                                                   \
+            QFS_LOAD_B(0, (kg_) * QF_KS + i_)                                                      \
+        }                                                                                          \
+        _Pragma("unroll") for (int j_ = 0; j_ < WN; j_++)                                          \
+            _Pragma("unroll") for (int l_ = 0; l_ < LA; l_++)                                      \
+                acc[j_][l_] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[i_], bf[PFB ? (i_ & 1) : 0][j_ * LA + l_], acc[j_][l_], 0, 0, 0); \
+        if constexpr (PFB) {                                                                       \
+            _Pragma("unroll") for (int t_ = 0; t_ < NBF; t_++) {                                   \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                 \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
+            }                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+        }                                                                                          \
+    }
+    QFS_LOAD_GROUP(av, mb_begin + wave, 0)
+    if constexpr (PFB) { QFS_LOAD_B(0, 0) }
+    for (uint64_t mb = mb_begin + wave; mb < mb_end; mb += QF_NW) {
+        v16i acc[WN][LA];
+#pragma unroll
+        for (int j = 0; j < WN; j++)
+#pragma unroll
+            for (int l = 0; l < LA; l++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[j][l][r] = 0;
+        for (uint32_t kg = 0; kg + 1 < G; kg++) {
+            QFS_LOAD_GROUP(avn, mb, kg + 1)
+            __builtin_amdgcn_sched_barrier(0);
+            QFS_GROUP(kg)
+#pragma unroll
+            for (int i = 0; i < QF_KS; i++) av[i] = avn[i];
+        }
+        // ---- last group: the next block's first group and the addend words of the whole tile are requested
+        // first and land under its MFMAs
+        const uint64_t mbn = mb + QF_NW < mb_end ? mb + QF_NW : mb;   // no next block: a harmless re-read
+        QFS_LOAD_GROUP(avn, mbn, 0)
+        const uint64_t mu0 = mb * 32;
+        const int64_t mleft = (int64_t)a.B - (int64_t)mu0;
+        const uint32_t mlim = mleft > 32 ? 32u : (uint32_t)mleft;                 // messages of this block inside the batch
+        uint32_t add[WN][16];
+#pragma unroll
+        for (int j = 0; j < WN; j++) {
+            const uint64_t col0 = (uint64_t)(rb0 + j) * 32;
+            const bool live = rb0 + j < a.rb;
+            const uint32_t nrec = live ? mlim * rowbytes - (uint32_t)col0 * 4 : 0;
+            const auto rs_add = __builtin_amdgcn_make_buffer_rsrc((void *)(a.addend + mu0 * a.rows + (live ? col0 : 0)), 0, a.addend ? (int)nrec : 0, 0x00020000);
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                add[j][r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_add, (int)(voff_st + ((r & 3) + 8 * (r >> 2)) * rowbytes), 0, 0);
+        }
+        uint32_t msgmask = 0;
+        if (tile_has_last) {
+            const uint64_t mrow_l = mu0 + ((uint32_t)lane & 31);
+            const bool bit = lane < 32 && mrow_l < a.B && (a.msg[mrow_l < a.B ? mrow_l : 0] & 1);
+            msgmask = (uint32_t)__ballot(bit);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        QFS_GROUP(G - 1)
+#pragma unroll
+        for (int i = 0; i < QF_KS; i++) av[i] = avn[i];
+        // ---- epilogue (as the one-digit path of qf_gemm_body: fp64, buffer descriptors whose record count is the batch bound)
+#pragma unroll
+        for (int j = 0; j < WN; j++) {
+            const uint32_t krow = (rb0 + j) * 32 + ((uint32_t)lane & 31);
+            if (rb0 + j >= a.rb || krow >= a.rows) continue;
+            const uint64_t col0 = (uint64_t)(rb0 + j) * 32;
+            const uint32_t nrec = mlim * rowbytes - (uint32_t)col0 * 4;
+            const auto rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + mu0 * a.rows + col0), 0, (int)nrec, 0x00020000);
+            const bool has_last = a.msg != nullptr && lastrow - (rb0 + j) * 32 < 32;
+            if (has_last) {
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    add[j][r] += (krow == lastrow && ((msgmask >> ((r & 3) + 8 * (r >> 2) + 4 * he)) & 1)) ? a.mod.qhalf : 0u;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int voff = (int)(voff_st + ((r & 3) + 8 * (r >> 2)) * rowbytes);
+#ifdef QF_ABL_SK_NOEPI
+                if (acc[j][0][r] == 0x7fffffff) __builtin_amdgcn_raw_buffer_store_b32(acc[j][S > 1 ? 1 : 0][r] + acc[j][S - 1][r] + (int)add[j][r], rs_out, voff, 0, 0);
+                continue;
+#endif
+#ifdef QF_ABL_SK_NOSTORE
+                { const int v_ = (int)qf_epi_f64<S>(acc[j][0][r], acc[j][S > 1 ? 1 : 0][r], acc[j][S > 2 ? 2 : 0][r], acc[j][S > 3 ? 3 : 0][r], (double)add[j][r], a);
+                  if (v_ == 0x7fffffff) __builtin_amdgcn_raw_buffer_store_b32(v_, rs_out, voff, 0, 0); }
+                continue;
+#endif
+                __builtin_amdgcn_raw_buffer_store_b32(
+                    (int)qf_epi_f64<S>(acc[j][0][r], acc[j][S > 1 ? 1 : 0][r], acc[j][S > 2 ? 2 : 0][r], acc[j][S > 3 ? 3 : 0][r], (double)add[j][r], a),
+                    rs_out, voff, 0, 0);
+            }
+        }
+    }
+#undef QFS_MB
+#undef QFS_LOAD_GROUP
+#undef QFS_LOAD_B
+#undef QFS_GROUP
+}
+
+// units = column tiles x P message splits; P chosen so that the rounds of 256 workgroups (one per CU: the key
+// tile takes most of a CU's LDS) are as full as possible while a unit keeps enough message blocks to amortise
+// loading its tile
+template <int LA, int WN>
+static int qf_gemm_dispatch_shortk(qf_ctx *ctx, const QfGemmArgs &args) {
+    const size_t lds = (size_t)WN * args.ks * LA * 1024;
+    static QfPerDevice attr;
+    QF_HIP(ctx, attr.once(ctx->device, [&] { return hipFuncSetAttribute((const void *)qf_gemm_shortk_kernel<LA, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }));
+    const uint32_t nct = (args.rb + WN - 1) / WN;
+    const uint64_t nmb = (args.B + 31) / 32;
+    int ncu = 256;
+    if (const char *e = getenv("QF_GEMM_SHORTK_CUS")) ncu = atoi(e) > 0 ? atoi(e) : ncu;
+    uint32_t bestP = 1;
+    double best = 1e300;
+    for (uint32_t P = 1; P <= 512; P++) {
+        const uint64_t per = (nmb + P - 1) / P;
+        if (P > 1 && per < 4 * QF_NW) break;                      // at least 4 blocks per wave and unit
+        const uint64_t units = (uint64_t)nct * P;
+        const double cost = (double)((units + ncu - 1) / ncu) * ((double)((per + QF_NW - 1) / QF_NW) + 1.5);   // + ~1.5 block times to load the tile
+        if (cost < best) { best = cost; bestP = P; }
+    }
+    if (const char *e = getenv("QF_GEMM_SHORTK_P")) bestP = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : bestP;
+    const uint32_t nunits = nct * bestP;
+    const uint32_t upx = (nunits + 7) / 8;
+    QfTimer t(ctx, &ctx->ms_gemm);
+    hipLaunchKernelGGL((qf_gemm_shortk_kernel<LA, WN>), dim3(upx * 8), dim3(QF_NW * 64), lds, ctx->stream, args, bestP, nunits, upx);
+    QF_HIP(ctx, hipGetLastError());
+    return QF_OK;
+}
+// whether the short-K sweep serves a folded one-digit product: the tile's planes must fit a CU's LDS, and there
+// must be enough rows and messages for the sweep to pay (QF_GEMM_SHORTK=0/1 overrides: tests, A/B)
+static int qf_gemm_shortk_wn(const QfGemmArgs &p, int la) {
+    const uint64_t kib = (uint64_t)p.ks * la;
+    int wn = 2 * kib <= 144 ? 2 : 0;
+    const uint64_t nmb = (p.B + 31) / 32;
+    bool use = wn && p.rb >= 16 && nmb >= 256;
+    if (const char *e = getenv("QF_GEMM_SHORTK")) use = wn && atoi(e) != 0;
+    return use ? wn : 0;
+}
+
 // message tiles per raster chunk (see qf_gemm_raster); QF_GEMM_MCHUNK / QF_GEMM_MCHUNK_BITS override
 static uint32_t qf_gemm_mchunk(bool bits, uint64_t nmsgtiles, unsigned coltiles) {
     // digit planes: always (LPR 3.31 -> 2.82 ms, SIS with Z_q inputs 4.35 -> 3.98 ms); bit operands
@@ -1359,6 +1585,14 @@ int qf_launch_gemm(qf_ctx *ctx, const qf_key *key, const void *X, int x_is_bits,
         p.kplanes = key->fold_planes[lb];
         p.ks = key->ks * (uint32_t)lb;
         p.xlb_total = 1; p.xlb_off = 0;
+        if (qf_gemm_shortk_wn(p, la) == 2) {
+            switch (la) {
+                case 1: return qf_gemm_dispatch_shortk<1, 2>(ctx, p);
+                case 2: return qf_gemm_dispatch_shortk<2, 2>(ctx, p);
+                case 3: return qf_gemm_dispatch_shortk<3, 2>(ctx, p);
+                case 4: return qf_gemm_dispatch_shortk<4, 2>(ctx, p);
+            }
+        }
         switch (la) {
             case 1: return qf_gemm_dispatch<1, 1, false>(ctx, p);
             case 2: return qf_gemm_dispatch<2, 1, false>(ctx, p);

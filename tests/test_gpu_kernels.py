@@ -460,6 +460,45 @@ def test_discrete_gauss_sampler(ctx, q, n, s):
     assert chi2 < keep.sum() + 6 * np.sqrt(2 * keep.sum()), (chi2, keep.sum())
 
 
+@pytest.mark.parametrize("rows,cols,q,B,P", [
+    (70, 230, 7764299, 300, 0),         # 3 row blocks -> 2 column tiles, the second half empty; one unit per tile
+    (129, 256, 7764299, 2100, 3),       # 5 row blocks, batch ends inside a block, 3 message splits
+    (5314, 230, 7764299, 700, 2),       # DualRegev secure128 key (167 row blocks -> 84 tiles)
+    (100, 128, 1073741789, 515, 0),     # 4 key digits x 4 operand digits: K' = 512
+    (97, 500, 40961, 1030, 5),          # 2 x 2 digits, K' = 1024
+    (64, 2000, 251, 257, 0),            # 1 digit, K' = 2048 (the LDS limit)
+    (33, 40, 7764299, 1, 0),            # one message
+])
+@pytest.mark.parametrize("with_addend", [False, True])
+def test_matmul_short_k_sweep(ctx, monkeypatch, rows, cols, q, B, P, with_addend):
+    """qf_gemm_shortk_kernel (key tile resident in LDS, waves sweep message blocks on their own): forced on for
+    small shapes, against the oracle -- padded column tiles, ragged batches, message splits, addend + message
+    term on the last row, the two-step fp64 recombination, and the same product through the tiled kernel."""
+    monkeypatch.setenv("QF_GEMM_SHORTK", "1")
+    if P:
+        monkeypatch.setenv("QF_GEMM_SHORTK_P", str(P))
+    A = co.sample_uniform(SEED, 1, rows, rows * cols, q).reshape(rows, cols)
+    X = co.sample_uniform(SEED, 3, 11, B * cols, q).reshape(B, cols)
+    e = co.sample_uniform(SEED, 4, 5, B * rows, q).reshape(B, rows) if with_addend else None
+    msg = co.sample_uniform(SEED, 5, 0, B, 2).astype(np.uint8) if with_addend else None
+    key = ctx.key_upload(A, q)
+    ref = co.matmul_batch(A, q, X, co.X_U32, B, addend=e, msg=msg, mt=True)
+    dX = ctx.to_dev_u32(X)
+    de = ctx.to_dev_u32(e) if with_addend else None
+    dm = ctx.to_dev_u8(msg) if with_addend else None
+    guard = ctx.empty_u32(B + 2, rows)
+    guard.fill_(-1)
+    out = ctx.matmul(key, dX, X_U32, B, addend=de, msg=dm, out=guard[1:B + 1])
+    assert np.array_equal(ctx.to_host_u32(out), ref)
+    g = ctx.to_host_u32(guard)
+    assert (g[0] == 0xFFFFFFFF).all() and (g[B + 1] == 0xFFFFFFFF).all()      # nothing written around the batch
+    monkeypatch.setenv("QF_GEMM_EPI2", "1")
+    assert np.array_equal(ctx.to_host_u32(ctx.matmul(key, dX, X_U32, B, addend=de, msg=dm)), ref)
+    monkeypatch.delenv("QF_GEMM_EPI2")
+    monkeypatch.setenv("QF_GEMM_SHORTK", "0")
+    assert np.array_equal(ctx.to_host_u32(ctx.matmul(key, dX, X_U32, B, addend=de, msg=dm)), ref)
+
+
 def test_keyed_samplers_match_the_oracle(ctx):
     """qf_sample_*_keyed_dev (ChaCha20 under a 256-bit key: what an object constructed without a seed draws
     from) against the oracle's restatement, which RFC 7539's block vector pins (tests/test_oracle_golden.py):

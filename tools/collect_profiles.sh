@@ -4,7 +4,7 @@ tag=$1; round=$2
 for d in gpurun_out/prof_$tag/*/; do
   wl=$(basename $d)
   mkdir -p profiles/$round/$wl
-  for f in kernel_stats.csv traffic.json mfma_util.json rocprofv3_kernel_stats.csv bench_trace.json command.txt; do
+  for f in kernel_stats.csv traffic.json mfma_util.json l2.json rocprofv3_kernel_stats.csv bench_trace.json command.txt; do
     [ -f $d/$f ] && cp $d/$f profiles/$round/$wl/$f
   done
 done

@@ -5,7 +5,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from crypto_amd.device import Context, X_BITS
 ctx = Context(0)
-if "lpr" in sys.argv[1:]:
+if "dualregev" in sys.argv[1:]:
+    from crypto_amd.device import X_U32
+    n, m, q, B = 230, 5313, 7764299, 1 << 16
+    key = ctx.key_upload(ctx.sample_uniform(1, 1, 0, (m + 1) * n, q).view(m + 1, n), q)
+    sv = ctx.sample_uniform(1, 3, 0, B * n, q).view(B, n)
+    e = ctx.sample_noise(1, 4, 0, B * (m + 1), q, 2951).view(B, m + 1)
+    out = ctx.empty_u32(B, m + 1)
+    nwaves = (B // 256) * 42 * 8          # <3,1,4> tiles: 167 row blocks / 4
+    run = lambda: ctx.matmul(key, sv, X_U32, B, addend=e, out=out)
+elif "lpr" in sys.argv[1:]:
     from crypto_amd.device import X_U32
     n, q, B = 1024, 1073741789, 1 << 17
     pk = ctx.sample_uniform(1, 1, 0, (n + 1) * n, q).view(n + 1, n)

@@ -64,6 +64,28 @@ if f:
     json.dump(mf, open(os.path.join(d, "mfma_util.json"), "w"), indent=1)
     for k, v in mf.items():
         print("MFMA", k, v)
+# L2 pass (GEMM workloads): hit / miss counts and fabric read requests per launch
+f = find("pmc_l2/**/*counter_collection.csv")
+if f:
+    tmp = collections.defaultdict(dict)
+    for r in csv.DictReader(open(f)):
+        key = (r["Dispatch_Id"], short(r["Kernel_Name"]))
+        tmp[key][r["Counter_Name"]] = tmp[key].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    for (_, k), m in tmp.items():
+        for n, v in m.items():
+            per[k][n].append(v)
+    l2 = {}
+    for k, c in per.items():
+        m = {n: sum(v[len(v) // 2:]) / max(1, len(v[len(v) // 2:])) for n, v in c.items()}
+        hit, miss = m.get("TCC_HIT_sum", 0), m.get("TCC_MISS_sum", 0)
+        if hit + miss < 1e5:
+            continue
+        l2[k] = {"launches": len(next(iter(c.values()))), **{n: round(v) for n, v in m.items()},
+                 "l2_hit_rate": round(hit / (hit + miss), 4) if hit + miss else None}
+    json.dump(l2, open(os.path.join(d, "l2.json"), "w"), indent=1)
+    for k, v in l2.items():
+        print("L2", k, v)
 with open(os.path.join(d, "kernel_stats.csv"), "w", newline="") as fo:
     w = csv.DictWriter(fo, fieldnames=list(rows[0].keys()) if rows else ["kernel"])
     w.writeheader(); w.writerows(rows)
