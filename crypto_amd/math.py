@@ -190,7 +190,8 @@ class MatPolyOverZ:
     def from_str(s: str, n: int) -> "MatPolyOverZ":
         inner = s.strip()
         inner = inner[inner.index("[[") + 2: inner.rindex("]]")]
-        return MatPolyOverZ([parse_poly(p) for p in inner.split(",")], n)
+        # a row "[[p0, p1, ...]]" or a column "[[p0],[p1],...]" (the reference's signatures are columns)
+        return MatPolyOverZ([parse_poly(p.strip(" []")) for p in inner.split(",")], n)
 
 
 def gaussian_width(s: Fraction | float) -> int:

@@ -548,6 +548,58 @@ def test_replay_fixtures_on_device(ctx):
     assert np.array_equal(ctx.to_host_u32(ctx.ring(n, q).polymul(ctx.to_dev_u32(a), ctx.to_dev_u32(b))), cc)
 
 
+def test_replay_fixtures_round3_on_device(ctx):
+    """The round-3 fixtures (Regev::dec incl. the tie of the decision rule, DualRegev enc/dec, RingLPR enc/dec incl. tie
+    coefficients, PSFGPVRing::f_a at n = 8 / q = 512, hash_to_mat_zq_sha256): the device reproduces every expected value
+    that tests/golden/replay/replay_test.rs asserts of the real reference."""
+    import os
+    from crypto_amd.math import MatPolyOverZ, MatZ, MatZq, parse_poly
+    path = os.path.join(os.path.dirname(__file__), "golden", "replay", "fixtures.txt")
+    f = dict(l.split("=", 1) for l in open(path).read().splitlines() if "=" in l)
+    u32 = lambda m: np.ascontiguousarray(m.entries.astype(np.uint32))
+    # Regev::dec: w = -s, the six ciphertexts as one batch
+    sk = MatZq.from_str(f["regev_dec_sk"])
+    q = sk.q
+    Cm = np.stack([u32(MatZq.from_str(f[f"regev_dec_c{k}"]))[:, 0] for k in range(int(f["regev_dec_count"]))])
+    w = ((q - u32(sk)[:, 0].astype(np.int64)) % q).astype(np.uint32)
+    assert ctx.to_host_u8(ctx.dot_decode(ctx.to_dev_u32(w), q, ctx.to_dev_u32(Cm))).tolist() == [int(b) for b in f["regev_dec_bits"].split()]
+    # DualRegev: transposed key, full-width operand s, then c^t [-x ; 1]
+    pk, s, e = (MatZq.from_str(f[k]) for k in ("dualregev_pk", "dualregev_s", "dualregev_e"))
+    x = MatZ.from_str(f["dualregev_sk"]).entries[:, 0].astype(np.int64)
+    q = pk.q
+    key = ctx.key_upload(u32(pk), q, transpose=True)
+    wx = ctx.to_dev_u32(((q - x) % q).astype(np.uint32))
+    for msg in (0, 1):
+        c = ctx.matmul(key, ctx.to_dev_u32(u32(s).T.copy()), X_U32, 1, addend=ctx.to_dev_u32(u32(e).T.copy()), msg=ctx.to_dev_u8(np.array([msg], np.uint8)))
+        assert ctx.to_host_u32(c)[0].tolist() == [int(t) for t in MatZq.from_str(f[f"dualregev_c{msg}"]).entries[:, 0]]
+        assert ctx.to_host_u8(ctx.dot_decode(wx, q, c)).tolist() == [msg]
+    # RingLPR (q = 2399: not NTT-friendly, the exact schoolbook kernel -- the reference's own default set)
+    n, q = int(f["ringlpr_n"]), int(f["ringlpr_q"])
+    P = lambda k: np.array(parse_poly(f[k]) + [0] * (n - len(parse_poly(f[k]))), np.uint32)
+    ring = ctx.ring(n, q)
+    pkr = ring.key(np.stack([P("ringlpr_a"), P("ringlpr_b")]))
+    mu = np.packbits((P("ringlpr_mu_q_half") != 0).astype(np.uint8)[None, :], axis=1, bitorder="little")
+    d = lambda k: ctx.to_dev_u32(P(k)[None])
+    u, v = ring.ringlpr_enc(pkr, d("ringlpr_r"), d("ringlpr_e1"), d("ringlpr_e2"), ctx.to_dev_u8(mu))
+    assert np.array_equal(ctx.to_host_u32(u)[0], P("ringlpr_u")) and np.array_equal(ctx.to_host_u32(v)[0], P("ringlpr_v"))
+    skr = ring.key(P("ringlpr_sk")[None])
+    as_int = lambda t: int.from_bytes(bytes(ctx.to_host_u8(t)[0]), "little")
+    assert as_int(ring.ringlpr_dec(skr, u, v)) == int(f["ringlpr_message"])
+    assert as_int(ring.ringlpr_dec(skr, ctx.to_dev_u32(np.zeros((1, n), np.uint32)), d("ringlpr_tie_v"))) == int(f["ringlpr_tie_message"])
+    # f_a inside the fused verification kernel (t returned, compared with u = t: accepted)
+    n, q = int(f["fa_n"]), int(f["fa_q"])
+    A = MatPolyOverZ.from_str(f["fa_a"], n).entries.astype(np.uint32)
+    sig = MatPolyOverZ.from_str(f["fa_sigma"], n).entries.astype(np.int32)
+    t_want = MatPolyOverZ.from_str(f["fa_t"], n).entries.astype(np.uint32)
+    ring = ctx.ring(n, q)
+    ok, t = ring.fdh_verify(ring.key(A), ctx.to_dev_i32(sig[None]), ctx.to_dev_u32(t_want), 100 * 100 * n * 11, want_t=True)
+    assert np.array_equal(ctx.to_host_u32(t), t_want) and ctx.to_host_u8(ok).tolist() == [1]
+    # hash_to_mat_zq_sha256 on the device
+    for key_, rows, cols, qq in (("hash_8x1_512", 8, 1, 512), ("hash_3x2_big", 3, 2, 1073479681)):
+        h = ctx.to_host_u32(ctx.hash_to_mat_zq_sha256([f["hash_msg"]], rows, cols, qq)).reshape(rows, cols)
+        assert h.tolist() == MatZq.from_str(f[key_]).entries.astype(np.int64).tolist()
+
+
 @pytest.mark.parametrize("rows", [65, 74, 130, 194, 257, 266])
 @pytest.mark.parametrize("q", [251, 65521, 16777213])
 def test_matmul_bits_packed_remainder_as_extra_fragment(ctx, monkeypatch, rows, q):

@@ -327,3 +327,65 @@ def test_replay_fixtures_match_the_c_oracle():
     pad = lambda p: np.array([p + [0] * (n - len(p))], np.uint32)
     a, b, cc = (pad(parse_poly(f[k])) for k in ("ring_a", "ring_b", "ring_c"))
     assert np.array_equal(co.polymul_batch(a, b, q), cc)
+
+
+def test_replay_fixtures_round3_products_match_the_c_oracle():
+    """The fixtures added in round 3 (every remaining product of SURVEY 8a: Regev::dec with the tie of the decision
+    rule, DualRegev enc/dec, RingLPR enc/dec, PSFGPVRing::f_a at n = 8 / q = 512, hash_to_mat_zq_sha256): the
+    expected values were written by the exact Python oracle; here the C restatement recomputes every one."""
+    from crypto_amd.math import MatPolyOverZ
+    f, MatZq, MatZ, parse_poly = _replay()
+    u32 = lambda m: np.ascontiguousarray(m.entries.astype(np.uint32))
+    # Regev::dec
+    sk = MatZq.from_str(f["regev_dec_sk"])
+    q = sk.q
+    want = [int(b) for b in f["regev_dec_bits"].split()]
+    Cm = np.stack([u32(MatZq.from_str(f[f"regev_dec_c{k}"]))[:, 0] for k in range(int(f["regev_dec_count"]))])
+    assert co.dot_decode_batch(u32(sk)[:, 0], q, Cm).tolist() == want
+    s_ = [int(v) for v in u32(sk)[:, 0]]
+    inner = lambda c: (sum((-a) * int(b) for a, b in zip(s_, c[:-1])) + int(c[-1])) % q
+    assert inner(Cm[2]) == (q + q // 2) // 2 and want[2] == 0          # the tie decides 0
+    assert [inner(Cm[0]), inner(Cm[1])] == [0, q // 4]
+    # DualRegev enc / dec
+    pk, s, e = (MatZq.from_str(f[k]) for k in ("dualregev_pk", "dualregev_s", "dualregev_e"))
+    x = MatZ.from_str(f["dualregev_sk"])
+    q = pk.q
+    pkT = np.ascontiguousarray(u32(pk).T)
+    for msg in (0, 1):
+        c = co.matmul_batch(pkT, q, u32(s).T.copy(), co.X_U32, 1, addend=u32(e).T.copy(), msg=np.array([msg], np.uint8))
+        assert c[0].tolist() == [int(t) for t in MatZq.from_str(f[f"dualregev_c{msg}"]).entries[:, 0]]
+        assert co.dualregev_decode_batch(x.entries[:, 0].astype(np.int32), q, c).tolist() == [msg]
+    # RingLPR enc / dec
+    n, q = int(f["ringlpr_n"]), int(f["ringlpr_q"])
+    P = lambda k: np.array(parse_poly(f[k]) + [0] * (n - len(parse_poly(f[k]))), np.uint32)
+    mu_bits = (P("ringlpr_mu_q_half") != 0).astype(np.uint8)
+    packed = np.packbits(mu_bits[None, :], axis=1, bitorder="little")
+    u, v = co.ringlpr_enc_batch(P("ringlpr_a"), P("ringlpr_b"), q, P("ringlpr_r")[None], P("ringlpr_e1")[None], P("ringlpr_e2")[None], packed)
+    assert np.array_equal(u[0], P("ringlpr_u")) and np.array_equal(v[0], P("ringlpr_v"))
+    as_int = lambda b: int.from_bytes(bytes(b), "little")
+    assert as_int(co.ringlpr_dec_batch(P("ringlpr_sk"), q, u, v)[0]) == int(f["ringlpr_message"])
+    assert as_int(co.ringlpr_dec_batch(P("ringlpr_sk"), q, np.zeros((1, n), np.uint32), P("ringlpr_tie_v")[None])[0]) == int(f["ringlpr_tie_message"])
+    assert (int(f["ringlpr_tie_message"]) >> 11) & 1 == 0 and P("ringlpr_tie_v")[11] == (q + q // 2) // 2    # the tie coefficient decides 0
+    # f_a
+    n, q = int(f["fa_n"]), int(f["fa_q"])
+    A = MatPolyOverZ.from_str(f["fa_a"], n).entries.astype(np.uint32)
+    sig = MatPolyOverZ.from_str(f["fa_sigma"], n).entries.astype(np.int32)
+    t_want = MatPolyOverZ.from_str(f["fa_t"], n).entries.astype(np.uint32)
+    assert A.shape == (11, n) and sig.shape == (11, n)
+    t, ok = co.fdh_ring_verify_batch(A, q, sig[None], t_want, 100 * 100 * n * 11)
+    assert np.array_equal(t, t_want) and ok.tolist() == [1]
+    # hash_to_mat_zq_sha256
+    assert co.hash_to_mat_zq(f["hash_msg"], 8, 1, 512).tolist() == MatZq.from_str(f["hash_8x1_512"]).entries.astype(np.int64).tolist()
+    assert co.hash_to_mat_zq(f["hash_msg"], 3, 2, 1073479681).tolist() == MatZq.from_str(f["hash_3x2_big"]).entries.astype(np.int64).tolist()
+
+
+def test_replay_rust_test_covers_every_fixture_key():
+    """replay_test.rs (uncompiled here) must read every key make_replay.py writes, and nothing else."""
+    import re
+    f, *_ = _replay()
+    rs = open(os.path.join(os.path.dirname(__file__), "golden", "replay", "replay_test.rs")).read()
+    used = set(re.findall(r'f\["([a-z0-9_]+)"\]', rs)) | set(re.findall(r'&f, "([a-z0-9_]+)"', rs))
+    fmt = re.findall(r'format!\("([a-z_]+)\{', rs)                     # regev_dec_c{k}, dualregev_c{msg}
+    covered = {k for k in f if k in used or any(k.startswith(p) for p in fmt)}
+    assert not set(f) - covered - {"regev_dec_count"}, sorted(set(f) - covered)
+    assert used <= set(f), sorted(used - set(f))
