@@ -30,6 +30,66 @@ def test_library_exports_every_declared_symbol():
     assert lib.qf_version().startswith(b"qfgpu")
 
 
+def _c_to_rust(ctype: str) -> str:
+    """One C parameter / return type of include/qfgpu.h as the Rust FFI type that must stand for it."""
+    t = re.sub(r"/\*.*?\*/", "", ctype).strip()
+    base = {"int": "c_int", "void": "c_void", "char": "c_char", "uint32_t": "u32", "uint64_t": "u64", "uint8_t": "u8", "int32_t": "i32",
+            "size_t": "usize", "double": "f64", "float": "f32", "qf_ctx": "qf_ctx", "qf_key": "qf_key", "qf_ring": "qf_ring", "qf_rkey": "qf_rkey"}
+    toks = re.findall(r"[A-Za-z_0-9]+|\*", t)
+    # C declarators read right to left: "const T *" = pointer to const T; "T *const *" = pointer to const pointer to T
+    const_base = toks[0] == "const"
+    if const_base:
+        toks = toks[1:]
+    out = base[toks[0]]
+    inner_const = const_base
+    for tok in toks[1:]:
+        if tok == "*":
+            out = ("*const " if inner_const else "*mut ") + out
+            inner_const = False
+        elif tok == "const":
+            inner_const = True        # qualifies the pointer just formed: the NEXT '*' points to a const pointer
+        else:
+            raise AssertionError(f"unexpected token {tok!r} in C type {ctype!r}")
+    return out
+
+
+def test_rust_sys_crate_matches_the_header():
+    """rust/qfgpu-sys/src/lib.rs (uncompiled: no Rust toolchain here) declares EVERY function of include/qfgpu.h with
+    the same name, the same number of parameters and, parameter by parameter, the Rust type the C type maps to; the
+    constants agree; and the trait-impl crate calls nothing the -sys crate does not declare."""
+    header = open(os.path.join(ROOT, "include", "qfgpu.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    cdecl = {}
+    for ret, name, args in re.findall(r"^\s*((?:const\s+)?[a-z_0-9]+\s*\**)\s*(qf_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.M | re.S):
+        params = [] if args.strip() == "void" else [a.strip() for a in args.replace("\n", " ").split(",")]
+        ptypes = [re.sub(r"\s*[A-Za-z_0-9]+$", "", a) if not a.rstrip().endswith("*") else a for a in params]   # drop the parameter name
+        cdecl[name] = (ret.strip(), ptypes)
+    assert set(cdecl) == set(_lib.SYMBOLS), set(cdecl) ^ set(_lib.SYMBOLS)
+    rs = open(os.path.join(ROOT, "rust", "qfgpu-sys", "src", "lib.rs")).read()
+    rdecl = {}
+    for name, args, ret in re.findall(r"pub fn (qf_[a-z0-9_]+)\(([^)]*)\)\s*(?:->\s*([^;]+))?;", rs):
+        ptypes = [a.split(":", 1)[1].strip() for a in args.split(",") if a.strip()]
+        rdecl[name] = ((ret or "").strip(), ptypes)
+    assert set(rdecl) == set(cdecl), set(rdecl) ^ set(cdecl)
+    for name, (cret, cparams) in cdecl.items():
+        rret, rparams = rdecl[name]
+        assert len(rparams) == len(cparams), (name, cparams, rparams)
+        for i, (c, r) in enumerate(zip(cparams, rparams)):
+            assert _c_to_rust(c) == r, (name, i, c, r)
+        assert (cret == "void" and rret == "") or _c_to_rust(cret) == rret, (name, cret, rret)
+    for cname, val in re.findall(r"(QF_[A-Z0-9_]+)\s*=\s*(\d+)", header):
+        assert re.search(rf"pub const {cname}: c_int = {val};", rs), cname
+    gpu = open(os.path.join(ROOT, "rust", "qfall-crypto-gpu", "src", "lib.rs")).read()
+    called = set(re.findall(r"\b(qf_[a-z0-9_]+)\(", gpu))
+    assert called <= set(cdecl), called - set(cdecl)
+    for entry in ("qf_matmul_modq_dev", "qf_matvec_modq_host", "qf_vecmat_modq_host", "qf_dot_decode_dev", "qf_ringlpr_enc_dev",
+                  "qf_ringlpr_dec_dev", "qf_fdh_ring_verify_dev", "qf_hash_to_mat_zq_sha256_dev", "qf_polymul_dev"):
+        assert entry in called, entry
+    for impl in ("impl PKEncryptionScheme for RegevGpu", "impl PKEncryptionScheme for DualRegevGpu", "impl PKEncryptionScheme for LPRGpu",
+                 "impl PKEncryptionScheme for RingLPRGpu", "impl SignatureScheme for FdhGpvRingGpu", "pub fn hash(&self, value: &MatZq) -> MatZq"):
+        assert impl in gpu, impl
+
+
 def test_no_product_module_imports_the_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "crypto_amd")):
         for f in files:
