@@ -32,6 +32,22 @@
 #define WV_THREADS 256
 #define WV_WAVES 4
 
+// QF_STAMP (diagnostic build, tools/ntt_stamp.py): per-wave s_memtime sums of the POLYMUL path -- global loads
+// (issue + wait + range reduction), the two forward transforms, the pointwise product, the inverse transform,
+// the scaling + stores, and, inside the transforms, the LDS transposes on their own.
+#ifdef QF_STAMP
+#define WV_T(var_) unsigned long long var_; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var_) :: "memory"); __builtin_amdgcn_sched_barrier(0);
+#define WV_STP_PARAM , unsigned long long *stp_tr
+#define WV_STP_ARG , stp_tr
+static unsigned long long *g_wv_dbg = nullptr;
+extern "C" void qf_debug_set_buffer_ring(void *p) { g_wv_dbg = (unsigned long long *)p; }
+#else
+#define WV_T(var_)
+#define WV_STP_PARAM
+#define WV_STP_ARG
+#endif
+
 // ---- layouts ---------------------------------------------------------------------------------
 template <int LG, int P>
 struct Ph {
@@ -70,12 +86,46 @@ __host__ __device__ constexpr uint32_t qf_swz(uint32_t i) {
 }
 
 // ---- butterflies -----------------------------------------------------------------------------
+// low 32 bits of a*b + c in ONE instruction (v_mad_u64_u32; the upper half of its 64-bit addend is left
+// undefined: only the low word of the result is used).  Shoup's  hi*q - Y*w  is then mul_hi, mul_lo, mad
+// instead of mul_hi, mul_lo, mul_lo, sub -- with the NEGATED twiddle -w (forward table, negated when it is
+// copied into LDS / read as a scalar) or the negated modulus (everything of the form x*w - hi*q).
+#ifndef QF_NTT_MAD
+#define QF_NTT_MAD 0   // measured (profiles/r3/ntt_ablation.log): polymul -1.5 %, RingLPR enc -2 %, dec spills at 4 waves/SIMD, FDH +0.5 %
+#endif
+typedef uint32_t wv_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t wv_mad_lo(uint32_t a, uint32_t b_uniform, uint32_t c_lo) {
+#if QF_NTT_MAD
+    wv_u2 c, r;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wuninitialized"
+    c.x = c_lo;
+#pragma clang diagnostic pop
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c) : "vcc");
+    return r.x;
+#else
+    return a * b_uniform + c_lo;
+#endif
+}
+// x*w - floor(x*wp / 2^32)*q  (Shoup, result in [0,2q) for w < q), nq = -q mod 2^32
+__device__ __forceinline__ uint32_t wv_shoup(uint32_t x, uint32_t w, uint32_t wp, uint32_t q, uint32_t nq) {
+#if QF_NTT_MAD
+    return wv_mad_lo(__umulhi(x, wp), nq, x * w);
+#else
+    return x * w - __umulhi(x, wp) * q;
+#endif
+}
 template <bool LAZY>
 __device__ __forceinline__ void bf_fwd(uint32_t &X, uint32_t &Y, uint32_t w, uint32_t wp, uint32_t q, uint32_t q2) {
     if (LAZY) {
         // tn = -(Y*w mod q, lazy) mod 2^32: keeping the NEGATED product turns x + 2q - t into one
-        // three-operand add (5 simple ops per butterfly instead of 6)
+        // three-operand add (5 simple ops per butterfly instead of 6).  With QF_NTT_MAD the caller passes
+        // w NEGATED (mod 2^32): tn = hi*q + Y*(-w)
+#if QF_NTT_MAD
+        uint32_t tn = wv_mad_lo(__umulhi(Y, wp), q, Y * w);
+#else
         uint32_t tn = __umulhi(Y, wp) * q - Y * w;
+#endif
         uint32_t x = min(X, X - q2);           // [0,4q) -> [0,2q)
         X = x - tn;
         Y = x + q2 + tn;
@@ -94,7 +144,7 @@ __device__ __forceinline__ void bf_inv(uint32_t &X, uint32_t &Y, uint32_t w, uin
     if (LAZY) {  // inputs in [0,2q)
         uint32_t s = X + Y, d = X + q2 - Y;
         X = min(s, s - q2);
-        Y = d * w - __umulhi(d, wp) * q;
+        Y = wv_shoup(d, w, wp, q, 0u - q);
     } else {
         uint32_t s = X + Y, d = X - Y;
         X = min(s, s - q);
@@ -129,9 +179,11 @@ struct Wv {
                 if (uniform) {
                     const uint32_t ti = m + (L::cpart(r) >> (b + 1));
                     w = tw_g[ti]; wp = tw_g[N + ti];
+                    if (QF_NTT_MAD && FWD && LAZY) w = 0u - w;   // scalar: the lazy forward butterfly takes -w (the LDS copy is stored negated)
                 } else {
 #ifdef QF_ABL_NOTWLDS
                     w = tw_g[m]; wp = tw_g[N + m];
+                    if (QF_NTT_MAD && FWD && LAZY) w = 0u - w;
 #else
                     const uint2 t2 = tw_lds[m + ((lp | L::cpart(r)) >> (b + 1))];
                     w = t2.x; wp = t2.y;
@@ -144,10 +196,11 @@ struct Wv {
     }
 
     template <int PF, int PT>
-    static __device__ __forceinline__ void transpose(uint32_t (&x)[R], uint32_t lane, uint32_t *buf) {
+    static __device__ __forceinline__ void transpose(uint32_t (&x)[R], uint32_t lane, uint32_t *buf WV_STP_PARAM) {
 #ifdef QF_ABL_NOTRANSPOSE
         return;
 #endif
+        WV_T(tt0)
         const uint32_t wa = qf_swz<LG>(Ph<LG, PF>::lpart(lane)), ra = qf_swz<LG>(Ph<LG, PT>::lpart(lane));
 #pragma unroll
         for (int r = 0; r < R; r++) buf[wa ^ qf_swz<LG>(Ph<LG, PF>::cpart(r))] = x[r];
@@ -158,39 +211,51 @@ struct Wv {
         for (int r = 0; r < R; r++) x[r] = buf[ra ^ qf_swz<LG>(Ph<LG, PT>::cpart(r))];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+#ifdef QF_STAMP
+        WV_T(tt1)
+        if (stp_tr) *stp_tr += tt1 - tt0;
+#endif
     }
 
     // twf_last: the twiddle table as the LAST phase sees it (the same LDS array; a caller may pass a
     // pointer the compiler cannot see through to keep that phase's loads inside its loop)
     template <int P>
     static __device__ __forceinline__ void fwd_rec(uint32_t (&x)[R], uint32_t lane, uint32_t *buf, const uint2 *twf,
-                                                   const uint2 *twf_last, const uint32_t *tw_g, uint32_t q) {
+                                                   const uint2 *twf_last, const uint32_t *tw_g, uint32_t q WV_STP_PARAM) {
         stages<P, true>(x, lane, P + 1 < NP ? twf : twf_last, tw_g, q);
         if constexpr (P + 1 < NP) {
-            transpose<P, P + 1>(x, lane, buf);
-            fwd_rec<P + 1>(x, lane, buf, twf, twf_last, tw_g, q);
+            transpose<P, P + 1>(x, lane, buf WV_STP_ARG);
+            fwd_rec<P + 1>(x, lane, buf, twf, twf_last, tw_g, q WV_STP_ARG);
         }
     }
     template <int P>
     static __device__ __forceinline__ void inv_rec(uint32_t (&x)[R], uint32_t lane, uint32_t *buf, const uint2 *twi,
-                                                   const uint32_t *tw_g, uint32_t q) {
+                                                   const uint32_t *tw_g, uint32_t q WV_STP_PARAM) {
         stages<P, false>(x, lane, twi, tw_g, q);
         if constexpr (P > 0) {
-            transpose<P, P - 1>(x, lane, buf);
-            inv_rec<P - 1>(x, lane, buf, twi, tw_g, q);
+            transpose<P, P - 1>(x, lane, buf WV_STP_ARG);
+            inv_rec<P - 1>(x, lane, buf, twi, tw_g, q WV_STP_ARG);
         }
     }
     // x: natural order (idx = lane + 64 r), any value < 4q (lazy) / canonical -> NTT values in the
     // last phase's register order, in [0,4q) (lazy) / canonical
     static __device__ __forceinline__ void forward(uint32_t (&x)[R], uint32_t lane, uint32_t *buf, const uint2 *twf,
-                                                   const uint32_t *tw_g, uint32_t q, const uint2 *twf_last = nullptr) {
-        fwd_rec<0>(x, lane, buf, twf, twf_last ? twf_last : twf, tw_g, q);
+                                                   const uint32_t *tw_g, uint32_t q, const uint2 *twf_last = nullptr
+#ifdef QF_STAMP
+                                                   , unsigned long long *stp_tr = nullptr
+#endif
+    ) {
+        fwd_rec<0>(x, lane, buf, twf, twf_last ? twf_last : twf, tw_g, q WV_STP_ARG);
     }
     // x: last-phase order, [0,2q) (lazy) / canonical -> n * (inverse transform), natural order,
     // same ranges; the caller scales by n^-1
     static __device__ __forceinline__ void inverse(uint32_t (&x)[R], uint32_t lane, uint32_t *buf, const uint2 *twi,
-                                                   const uint32_t *tw_g_inv, uint32_t q) {
-        inv_rec<NP - 1>(x, lane, buf, twi, tw_g_inv, q);
+                                                   const uint32_t *tw_g_inv, uint32_t q
+#ifdef QF_STAMP
+                                                   , unsigned long long *stp_tr = nullptr
+#endif
+    ) {
+        inv_rec<NP - 1>(x, lane, buf, twi, tw_g_inv, q WV_STP_ARG);
     }
 };
 
@@ -239,11 +304,11 @@ __global__ __launch_bounds__(WV_THREADS, (wv_min_waves<LG, MODE>())) void qf_rin
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint32_t *buf = lds + 4 * N + wave * N;
     for (uint32_t e = tid; e < (uint32_t)N; e += WV_THREADS) {
-        twf[e] = make_uint2(a.tw[e], a.tw[N + e]);
+        twf[e] = make_uint2((QF_NTT_MAD && LAZY) ? 0u - a.tw[e] : a.tw[e], a.tw[N + e]);   // lazy forward butterflies take -w (bf_fwd)
         twi[e] = make_uint2(a.tw[2 * N + e], a.tw[3 * N + e]);
     }
     __syncthreads();
-    const uint32_t q = a.mod.q, q2 = 2 * q, one_p = a.one_p;
+    const uint32_t q = a.mod.q, q2 = 2 * q, one_p = a.one_p, nq = 0u - q;
     const uint32_t *twg_f = a.tw, *twg_i = a.tw + 2 * N;
     const uint32_t LI = Ph<LG, W::NP - 1>::lpart(lane);  // unused except for documentation of order
     (void)LI;
@@ -275,10 +340,19 @@ __global__ __launch_bounds__(WV_THREADS, (wv_min_waves<LG, MODE>())) void qf_rin
         if constexpr (MODE == MODE_RLPR_ENC) asm volatile("" ::: "memory");
         if constexpr (MODE == MODE_POLYMUL) {
             uint32_t xa[R], xb[R];
+            WV_T(ts0)
             load_nat(xa, a.in0 + item * N);
             load_nat(xb, a.in1 + item * N);
+            WV_T(ts1)
+#ifdef QF_STAMP
+            unsigned long long s_tr = 0;
+            W::forward(xa, lane, buf, twf, twg_f, q, nullptr, &s_tr);
+            W::forward(xb, lane, buf, twf, twg_f, q, nullptr, &s_tr);
+#else
             W::forward(xa, lane, buf, twf, twg_f, q);
             W::forward(xb, lane, buf, twf, twg_f, q);
+#endif
+            WV_T(ts2)
             // pointwise product in Montgomery form: a*b*2^-32 mod q with 4 multiplies (a 64-bit Barrett
             // product takes 10); the 2^-32 is absorbed by the final n^-1 scaling (ninv_m = n^-1 * 2^32).
             // a is canonicalised so that a*b < q*2^32 (b < 4q, q < 2^30 in the lazy variant).
@@ -290,13 +364,26 @@ __global__ __launch_bounds__(WV_THREADS, (wv_min_waves<LG, MODE>())) void qf_rin
                 const uint32_t v = hi - __umulhi(lo * a.qinv32, q) + q;   // (0, 2q)
                 xa[r] = LAZY ? v : min(v, v - q);
             }
+            WV_T(ts3)
+#ifdef QF_STAMP
+            W::inverse(xa, lane, buf, twi, twg_i, q, &s_tr);
+#else
             W::inverse(xa, lane, buf, twi, twg_i, q);
+#endif
+            WV_T(ts4)
             uint32_t *dst = a.out0 + item * N;
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                const uint32_t t = xa[r] * a.ninv_m - __umulhi(xa[r], a.ninv_m_p) * q;
+                const uint32_t t = wv_shoup(xa[r], a.ninv_m, a.ninv_m_p, q, nq);
                 (dst + lane)[64 * r] = min(t, t - q);
             }
+#ifdef QF_STAMP
+            WV_T(ts5)
+            if (a.dbg && lane == 0) {
+                unsigned long long *d = a.dbg + (((uint64_t)blockIdx.x * WV_WAVES + wave) * 8);
+                d[0] += ts1 - ts0; d[1] += ts2 - ts1; d[2] += ts3 - ts2; d[3] += ts4 - ts3; d[4] += ts5 - ts4; d[5] += s_tr; d[6] += 1; d[7] += ts5 - ts0;
+            }
+#endif
         } else if constexpr (MODE == MODE_FWD_ONLY) {
             // key preparation: interleaved (value, Shoup companion) pairs in last-phase register order
             uint32_t x[R];
@@ -306,7 +393,7 @@ __global__ __launch_bounds__(WV_THREADS, (wv_min_waves<LG, MODE>())) void qf_rin
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 // n^-1 goes into the key: the key-based modes then need no scaling after their inverse transforms
-                uint32_t v = x[r] * a.ninv - __umulhi(x[r], a.ninv_p) * q;
+                uint32_t v = wv_shoup(x[r], a.ninv, a.ninv_p, q, nq);
                 v = min(v, v - q);
                 (dst + lane)[64 * r] = make_uint2(v, (uint32_t)((((uint64_t)v) << 32) / q));
             }
@@ -327,7 +414,7 @@ __global__ __launch_bounds__(WV_THREADS, (wv_min_waves<LG, MODE>())) void qf_rin
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 uint2 k2 = (kha + lane)[64 * r];
-                uint32_t v = xr[r] * k2.x - __umulhi(xr[r], k2.y) * q;  // [0,2q)
+                uint32_t v = wv_shoup(xr[r], k2.x, k2.y, q, nq);  // [0,2q)
                 t[r] = LAZY ? v : min(v, v - q);
             }
             constexpr bool PRE2 = R <= 16;  // n = 2048: 128 data registers would spill
@@ -349,7 +436,7 @@ __global__ __launch_bounds__(WV_THREADS, (wv_min_waves<LG, MODE>())) void qf_rin
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 uint2 k2 = (khb + lane)[64 * r];
-                uint32_t v = xr[r] * k2.x - __umulhi(xr[r], k2.y) * q;
+                uint32_t v = wv_shoup(xr[r], k2.x, k2.y, q, nq);
                 t[r] = LAZY ? v : min(v, v - q);
             }
             W::inverse(t, lane, buf, twi, twg_i, q);
@@ -374,7 +461,7 @@ __global__ __launch_bounds__(WV_THREADS, (wv_min_waves<LG, MODE>())) void qf_rin
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 uint2 k2 = (kh + lane)[64 * r];
-                uint32_t v = x[r] * k2.x - __umulhi(x[r], k2.y) * q;
+                uint32_t v = wv_shoup(x[r], k2.x, k2.y, q, nq);
                 x[r] = LAZY ? v : min(v, v - q);
             }
             W::inverse(x, lane, buf, twi, twg_i, q);
@@ -425,7 +512,7 @@ __global__ __launch_bounds__(WV_THREADS, (wv_min_waves<LG, MODE>())) void qf_rin
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     uint2 k2 = (kh + lane)[64 * r];
-                    uint32_t v = x[r] * k2.x - __umulhi(x[r], k2.y) * q;  // [0,2q)
+                    uint32_t v = wv_shoup(x[r], k2.x, k2.y, q, nq);  // [0,2q)
                     if (LAZY) { uint32_t s = acc[r] + v; acc[r] = min(s, s - q2); }
                     else { v = min(v, v - q); uint32_t s = acc[r] + v; acc[r] = min(s, s - q); }
                 }
@@ -456,8 +543,12 @@ __global__ __launch_bounds__(WV_THREADS, (wv_min_waves<LG, MODE>())) void qf_rin
 
 // ---- launcher --------------------------------------------------------------------------------
 template <int LG, int MODE>
-static int wv_launch(qf_ctx *ctx, const qf_ring *ring, const QfRingArgs &a) {
+static int wv_launch(qf_ctx *ctx, const qf_ring *ring, const QfRingArgs &a_in) {
     constexpr int N = 1 << LG;
+    QfRingArgs a = a_in;
+#ifdef QF_STAMP
+    a.dbg = g_wv_dbg;
+#endif
     const size_t lds = (size_t)(4 * N + WV_WAVES * N) * 4;
     uint64_t blocks = (a.B + WV_WAVES - 1) / WV_WAVES;
     if (blocks > 256 * 8) blocks = 256 * 8;  // persistent beyond that: waves loop over items

@@ -28,6 +28,7 @@ struct QfRingArgs {
     const uint32_t *u;                // FDH: hashed targets (B x n)
     uint8_t *ok;                      // FDH: verdicts
     uint64_t norm_bound;              // FDH: floor(s^2 * n * mbar)
+    unsigned long long *dbg = nullptr; // diagnostic build only (QF_STAMP): per-wave cycle sums of the POLYMUL path
 };
 
 // qf_ntt_wave.hip: wave-per-polynomial kernels for n = 256..2048 on NTT-friendly q.  Ring keys of
