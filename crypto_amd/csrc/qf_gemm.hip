@@ -1174,7 +1174,12 @@ __global__ __launch_bounds__(QF_NW * 64, 2) void qf_gemm_packedx_kernel(QfGemmAr
 // Work units (column tile c, message split p) are dealt to the XCDs in runs: unit u = c*P + p goes
 // to XCD u / upx, so the workgroups that share a stream of operand planes (same p, neighbouring c)
 // and the output lines that straddle two column tiles meet in ONE L2.
-template <int LA, int WN>
+// MW = message blocks (of 32) a wave multiplies per key fragment it reads from LDS.  One 1-KiB fragment read per
+// 32-cycle MFMA and SIMD is exactly the LDS port's 128 B/clk/CU: at MW = 1 the matrix pipe and the LDS port run at
+// the same limit (measured: the main loop alone reaches 0.63 of both).  <WN = 1, MW = 2> halves the LDS reads per
+// MFMA at the same accumulator count (the operand planes are then read from L2 once per row block instead of
+// once per two).
+template <int LA, int WN, int MW>
 __global__ __launch_bounds__(QF_NW * 64, 2) void qf_gemm_shortk_kernel(QfGemmArgs a, uint32_t P, uint32_t nunits, uint32_t upx) {
     constexpr int S = LA;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // WN * ks * LA KiB
@@ -1185,9 +1190,10 @@ __global__ __launch_bounds__(QF_NW * 64, 2) void qf_gemm_shortk_kernel(QfGemmArg
     if (slot >= upx || u >= nunits) return;                       // uniform: whole workgroup
     const uint32_t c = u / P, p = u % P;
     const uint32_t rb0 = c * WN;
-    const uint64_t nmb = (a.B + 31) / 32;
-    const uint64_t per = (nmb + P - 1) / P;
-    const uint64_t mb_begin = p * per, mb_end = mb_begin + per < nmb ? mb_begin + per : nmb;
+    const uint64_t nmb = (a.B + 31) / 32;                         // message blocks
+    const uint64_t nmp = (nmb + MW - 1) / MW;                     // groups of MW blocks: a wave's unit of work
+    const uint64_t per = (nmp + P - 1) / P;
+    const uint64_t mp_begin = p * per, mp_end = mp_begin + per < nmp ? mp_begin + per : nmp;
     const uint32_t fprb = a.ks * LA;                              // fragments (KiB) per row block
 
     // ---- the column tile's planes -> LDS, image [j][k-step][digit][64 lanes][16 B] = the HBM order of a row block
@@ -1201,7 +1207,7 @@ __global__ __launch_bounds__(QF_NW * 64, 2) void qf_gemm_shortk_kernel(QfGemmArg
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (mb_begin + wave >= mb_end) return;
+    if (mp_begin + wave >= mp_end) return;
 
     const uint32_t lastrow = a.rows - 1;
     const uint32_t rowbytes = a.rows * 4;
@@ -1214,20 +1220,22 @@ __global__ __launch_bounds__(QF_NW * 64, 2) void qf_gemm_shortk_kernel(QfGemmArg
     // Operand registers: av = the group of 4 k-steps being multiplied, avn = the next one (requested at the top
     // of the current group: the last group of a block requests the first group of the wave's next block);
     // bf = the key fragments of the current and the next k-step (LDS reads one k-step ahead, one read between
-    // consecutive MFMAs; the k-step behind a block's last one is k-step 0 again: the tile is the same for every
-    // block, so the read-ahead simply wraps around).
+    // consecutive MFMA groups; the k-step behind a block's last one is k-step 0 again: the tile is the same for
+    // every block, so the read-ahead simply wraps around).
 #ifdef QF_ABL_SK_HOTX
 #define QFS_MB(m_) ((m_) & 7)      /* ablation: every wave re-reads the same 8 blocks of operand planes (L1/L2-hot) */
 #else
 #define QFS_MB(m_) (m_)
 #endif
     constexpr int NBF = WN * LA;
-    constexpr bool PFB = NBF * 16 + 2 * NBF * 4 + 8 * QF_KS + WN * 16 <= 216;   // LA = 4: no registers for the second fragment set
-    v4i av[QF_KS], avn[QF_KS], bf[PFB ? 2 : 1][NBF];
-#define QFS_LOAD_GROUP(dst_, mb_, kg_)                                                             \
-    {                                                                                              \
-        const int8_t *x_ = a.xplanes + ((size_t)QFS_MB(mb_) * a.ks + (size_t)(kg_) * QF_KS) * 1024 + (size_t)lane * 16; \
-        _Pragma("unroll") for (int i_ = 0; i_ < QF_KS; i_++) dst_[i_] = *(const v4i *)(x_ + i_ * 1024); \
+    constexpr bool PFB = MW * NBF * 16 + 2 * NBF * 4 + MW * 8 * QF_KS + MW * WN * 16 <= 216;   // LA = 4: no registers for the second fragment set
+    v4i av[MW][QF_KS], avn[MW][QF_KS], bf[PFB ? 2 : 1][NBF];
+    // block m of group mp_ (clamped to the last block of the batch: its results are dropped by the epilogue's record counts)
+#define QFS_BLOCK(mp_, m_) (((mp_) * MW + (m_)) < nmb ? ((mp_) * MW + (m_)) : nmb - 1)
+#define QFS_LOAD_GROUP(dst_, mp_, kg_)                                                             \
+    _Pragma("unroll") for (int m_ = 0; m_ < MW; m_++) {                                            \
+        const int8_t *x_ = a.xplanes + ((size_t)QFS_MB(QFS_BLOCK(mp_, m_)) * a.ks + (size_t)(kg_) * QF_KS) * 1024 + (size_t)lane * 16; \
+        _Pragma("unroll") for (int i_ = 0; i_ < QF_KS; i_++) dst_[m_][i_] = *(const v4i *)(x_ + i_ * 1024); \
     }
 #define QFS_LOAD_B(set_, k_)                                                                       \
     _Pragma("unroll") for (int j_ = 0; j_ < WN; j_++)                                              \
@@ -1244,93 +1252,109 @@ __global__ __launch_bounds__(QF_NW * 64, 2) void qf_gemm_shortk_kernel(QfGemmArg
         }                                                                                          \
         _Pragma("unroll") for (int j_ = 0; j_ < WN; j_++)                                          \
             _Pragma("unroll") for (int l_ = 0; l_ < LA; l_++)                                      \
-                acc[j_][l_] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[i_], bf[PFB ? (i_ & 1) : 0][j_ * LA + l_], acc[j_][l_], 0, 0, 0); \
+                _Pragma("unroll") for (int m_ = 0; m_ < MW; m_++)                                  \
+                    acc[m_][j_][l_] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[m_][i_], bf[PFB ? (i_ & 1) : 0][j_ * LA + l_], acc[m_][j_][l_], 0, 0, 0); \
         if constexpr (PFB) {                                                                       \
             _Pragma("unroll") for (int t_ = 0; t_ < NBF; t_++) {                                   \
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                 \
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
+                __builtin_amdgcn_sched_group_barrier(0x008, MW, 0);                                \
             }                                                                                      \
             __builtin_amdgcn_sched_barrier(0);                                                     \
         }                                                                                          \
     }
-    QFS_LOAD_GROUP(av, mb_begin + wave, 0)
+    QFS_LOAD_GROUP(av, mp_begin + wave, 0)
     if constexpr (PFB) { QFS_LOAD_B(0, 0) }
-    for (uint64_t mb = mb_begin + wave; mb < mb_end; mb += QF_NW) {
-        v16i acc[WN][LA];
+    for (uint64_t mp = mp_begin + wave; mp < mp_end; mp += QF_NW) {
+        v16i acc[MW][WN][LA];
 #pragma unroll
-        for (int j = 0; j < WN; j++)
+        for (int m = 0; m < MW; m++)
 #pragma unroll
-            for (int l = 0; l < LA; l++)
+            for (int j = 0; j < WN; j++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) acc[j][l][r] = 0;
+                for (int l = 0; l < LA; l++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[m][j][l][r] = 0;
         for (uint32_t kg = 0; kg + 1 < G; kg++) {
-            QFS_LOAD_GROUP(avn, mb, kg + 1)
+            QFS_LOAD_GROUP(avn, mp, kg + 1)
             __builtin_amdgcn_sched_barrier(0);
             QFS_GROUP(kg)
 #pragma unroll
-            for (int i = 0; i < QF_KS; i++) av[i] = avn[i];
+            for (int m = 0; m < MW; m++)
+#pragma unroll
+                for (int i = 0; i < QF_KS; i++) av[m][i] = avn[m][i];
         }
         // ---- last group: the next block's first group and the addend words of the whole tile are requested
         // first and land under its MFMAs
-        const uint64_t mbn = mb + QF_NW < mb_end ? mb + QF_NW : mb;   // no next block: a harmless re-read
-        QFS_LOAD_GROUP(avn, mbn, 0)
-        const uint64_t mu0 = mb * 32;
-        const int64_t mleft = (int64_t)a.B - (int64_t)mu0;
-        const uint32_t mlim = mleft > 32 ? 32u : (uint32_t)mleft;                 // messages of this block inside the batch
-        uint32_t add[WN][16];
+        const uint64_t mpn = mp + QF_NW < mp_end ? mp + QF_NW : mp;   // no next block: a harmless re-read
+        QFS_LOAD_GROUP(avn, mpn, 0)
+        uint32_t add[MW][WN][16], mlim[MW], msgmask[MW];
+        uint64_t mu0[MW];
 #pragma unroll
-        for (int j = 0; j < WN; j++) {
-            const uint64_t col0 = (uint64_t)(rb0 + j) * 32;
-            const bool live = rb0 + j < a.rb;
-            const uint32_t nrec = live ? mlim * rowbytes - (uint32_t)col0 * 4 : 0;
-            const auto rs_add = __builtin_amdgcn_make_buffer_rsrc((void *)(a.addend + mu0 * a.rows + (live ? col0 : 0)), 0, a.addend ? (int)nrec : 0, 0x00020000);
+        for (int m = 0; m < MW; m++) {
+            mu0[m] = (mp * MW + m) * 32;
+            const int64_t mleft = (int64_t)a.B - (int64_t)mu0[m];
+            mlim[m] = mleft > 32 ? 32u : (mleft > 0 ? (uint32_t)mleft : 0u);    // messages of this block inside the batch (0: a block past the end)
+            if (mlim[m] == 0) mu0[m] = 0;                                          // keeps the descriptor bases inside the buffers
 #pragma unroll
-            for (int r = 0; r < 16; r++)
-                add[j][r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_add, (int)(voff_st + ((r & 3) + 8 * (r >> 2)) * rowbytes), 0, 0);
-        }
-        uint32_t msgmask = 0;
-        if (tile_has_last) {
-            const uint64_t mrow_l = mu0 + ((uint32_t)lane & 31);
-            const bool bit = lane < 32 && mrow_l < a.B && (a.msg[mrow_l < a.B ? mrow_l : 0] & 1);
-            msgmask = (uint32_t)__ballot(bit);
+            for (int j = 0; j < WN; j++) {
+                const uint64_t col0 = (uint64_t)(rb0 + j) * 32;
+                const bool live = rb0 + j < a.rb && mlim[m] != 0;
+                const uint32_t nrec = live ? mlim[m] * rowbytes - (uint32_t)col0 * 4 : 0;
+                const auto rs_add = __builtin_amdgcn_make_buffer_rsrc((void *)(a.addend + mu0[m] * a.rows + (live ? col0 : 0)), 0, a.addend ? (int)nrec : 0, 0x00020000);
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    add[m][j][r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_add, (int)(voff_st + ((r & 3) + 8 * (r >> 2)) * rowbytes), 0, 0);
+            }
+            msgmask[m] = 0;
+            if (tile_has_last) {
+                const uint64_t mrow_l = mu0[m] + ((uint32_t)lane & 31);
+                const bool bit = lane < 32 && mlim[m] != 0 && mrow_l < a.B && (a.msg[mrow_l < a.B ? mrow_l : 0] & 1);
+                msgmask[m] = (uint32_t)__ballot(bit);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         QFS_GROUP(G - 1)
 #pragma unroll
-        for (int i = 0; i < QF_KS; i++) av[i] = avn[i];
+        for (int m = 0; m < MW; m++)
+#pragma unroll
+            for (int i = 0; i < QF_KS; i++) av[m][i] = avn[m][i];
         // ---- epilogue (as the one-digit path of qf_gemm_body: fp64, buffer descriptors whose record count is the batch bound)
+#pragma unroll
+        for (int m = 0; m < MW; m++) {
 #pragma unroll
         for (int j = 0; j < WN; j++) {
             const uint32_t krow = (rb0 + j) * 32 + ((uint32_t)lane & 31);
-            if (rb0 + j >= a.rb || krow >= a.rows) continue;
+            if (rb0 + j >= a.rb || krow >= a.rows || mlim[m] == 0) continue;
             const uint64_t col0 = (uint64_t)(rb0 + j) * 32;
-            const uint32_t nrec = mlim * rowbytes - (uint32_t)col0 * 4;
-            const auto rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + mu0 * a.rows + col0), 0, (int)nrec, 0x00020000);
+            const uint32_t nrec = mlim[m] * rowbytes - (uint32_t)col0 * 4;
+            const auto rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + mu0[m] * a.rows + col0), 0, (int)nrec, 0x00020000);
             const bool has_last = a.msg != nullptr && lastrow - (rb0 + j) * 32 < 32;
             if (has_last) {
 #pragma unroll
                 for (int r = 0; r < 16; r++)
-                    add[j][r] += (krow == lastrow && ((msgmask >> ((r & 3) + 8 * (r >> 2) + 4 * he)) & 1)) ? a.mod.qhalf : 0u;
+                    add[m][j][r] += (krow == lastrow && ((msgmask[m] >> ((r & 3) + 8 * (r >> 2) + 4 * he)) & 1)) ? a.mod.qhalf : 0u;
             }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int voff = (int)(voff_st + ((r & 3) + 8 * (r >> 2)) * rowbytes);
 #ifdef QF_ABL_SK_NOEPI
-                if (acc[j][0][r] == 0x7fffffff) __builtin_amdgcn_raw_buffer_store_b32(acc[j][S > 1 ? 1 : 0][r] + acc[j][S - 1][r] + (int)add[j][r], rs_out, voff, 0, 0);
+                if (acc[m][j][0][r] == 0x7fffffff) __builtin_amdgcn_raw_buffer_store_b32(acc[m][j][S > 1 ? 1 : 0][r] + acc[m][j][S - 1][r] + (int)add[m][j][r], rs_out, voff, 0, 0);
                 continue;
 #endif
 #ifdef QF_ABL_SK_NOSTORE
-                { const int v_ = (int)qf_epi_f64<S>(acc[j][0][r], acc[j][S > 1 ? 1 : 0][r], acc[j][S > 2 ? 2 : 0][r], acc[j][S > 3 ? 3 : 0][r], (double)add[j][r], a);
+                { const int v_ = (int)qf_epi_f64<S>(acc[m][j][0][r], acc[m][j][S > 1 ? 1 : 0][r], acc[m][j][S > 2 ? 2 : 0][r], acc[m][j][S > 3 ? 3 : 0][r], (double)add[m][j][r], a);
                   if (v_ == 0x7fffffff) __builtin_amdgcn_raw_buffer_store_b32(v_, rs_out, voff, 0, 0); }
                 continue;
 #endif
                 __builtin_amdgcn_raw_buffer_store_b32(
-                    (int)qf_epi_f64<S>(acc[j][0][r], acc[j][S > 1 ? 1 : 0][r], acc[j][S > 2 ? 2 : 0][r], acc[j][S > 3 ? 3 : 0][r], (double)add[j][r], a),
+                    (int)qf_epi_f64<S>(acc[m][j][0][r], acc[m][j][S > 1 ? 1 : 0][r], acc[m][j][S > 2 ? 2 : 0][r], acc[m][j][S > 3 ? 3 : 0][r], (double)add[m][j][r], a),
                     rs_out, voff, 0, 0);
             }
         }
+        }
     }
 #undef QFS_MB
+#undef QFS_BLOCK
 #undef QFS_LOAD_GROUP
 #undef QFS_LOAD_B
 #undef QFS_GROUP
@@ -1339,40 +1363,42 @@ __global__ __launch_bounds__(QF_NW * 64, 2) void qf_gemm_shortk_kernel(QfGemmArg
 // units = column tiles x P message splits; P chosen so that the rounds of 256 workgroups (one per CU: the key
 // tile takes most of a CU's LDS) are as full as possible while a unit keeps enough message blocks to amortise
 // loading its tile
-template <int LA, int WN>
+template <int LA, int WN, int MW>
 static int qf_gemm_dispatch_shortk(qf_ctx *ctx, const QfGemmArgs &args) {
     const size_t lds = (size_t)WN * args.ks * LA * 1024;
     static QfPerDevice attr;
-    QF_HIP(ctx, attr.once(ctx->device, [&] { return hipFuncSetAttribute((const void *)qf_gemm_shortk_kernel<LA, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }));
+    QF_HIP(ctx, attr.once(ctx->device, [&] { return hipFuncSetAttribute((const void *)qf_gemm_shortk_kernel<LA, WN, MW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }));
     const uint32_t nct = (args.rb + WN - 1) / WN;
-    const uint64_t nmb = (args.B + 31) / 32;
+    const uint64_t nmp = ((args.B + 31) / 32 + MW - 1) / MW;
     int ncu = 256;
     if (const char *e = getenv("QF_GEMM_SHORTK_CUS")) ncu = atoi(e) > 0 ? atoi(e) : ncu;
     uint32_t bestP = 1;
     double best = 1e300;
     for (uint32_t P = 1; P <= 512; P++) {
-        const uint64_t per = (nmb + P - 1) / P;
-        if (P > 1 && per < 4 * QF_NW) break;                      // at least 4 blocks per wave and unit
+        const uint64_t per = (nmp + P - 1) / P;
+        if (P > 1 && per < 4 * QF_NW) break;                      // at least 4 iterations per wave and unit
         const uint64_t units = (uint64_t)nct * P;
-        const double cost = (double)((units + ncu - 1) / ncu) * ((double)((per + QF_NW - 1) / QF_NW) + 1.5);   // + ~1.5 block times to load the tile
+        const double cost = (double)((units + ncu - 1) / ncu) * ((double)((per + QF_NW - 1) / QF_NW) + 1.5);   // + ~1.5 iterations to load the tile
         if (cost < best) { best = cost; bestP = P; }
     }
     if (const char *e = getenv("QF_GEMM_SHORTK_P")) bestP = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : bestP;
     const uint32_t nunits = nct * bestP;
     const uint32_t upx = (nunits + 7) / 8;
     QfTimer t(ctx, &ctx->ms_gemm);
-    hipLaunchKernelGGL((qf_gemm_shortk_kernel<LA, WN>), dim3(upx * 8), dim3(QF_NW * 64), lds, ctx->stream, args, bestP, nunits, upx);
+    hipLaunchKernelGGL((qf_gemm_shortk_kernel<LA, WN, MW>), dim3(upx * 8), dim3(QF_NW * 64), lds, ctx->stream, args, bestP, nunits, upx);
     QF_HIP(ctx, hipGetLastError());
     return QF_OK;
 }
 // whether the short-K sweep serves a folded one-digit product: the tile's planes must fit a CU's LDS, and there
-// must be enough rows and messages for the sweep to pay (QF_GEMM_SHORTK=0/1 overrides: tests, A/B)
+// must be enough rows and messages for the sweep to pay (QF_GEMM_SHORTK=0/1 overrides: tests, A/B).  Returns 0
+// (no), 2 (<WN = 2, MW = 1>) or 1 (<WN = 1, MW = 2>: QF_GEMM_SHORTK_MW=2).
 static int qf_gemm_shortk_wn(const QfGemmArgs &p, int la) {
     const uint64_t kib = (uint64_t)p.ks * la;
     int wn = 2 * kib <= 144 ? 2 : 0;
     const uint64_t nmb = (p.B + 31) / 32;
     bool use = wn && p.rb >= 16 && nmb >= 256;
     if (const char *e = getenv("QF_GEMM_SHORTK")) use = wn && atoi(e) != 0;
+    if (use && la <= 3) if (const char *e = getenv("QF_GEMM_SHORTK_MW")) if (atoi(e) == 2) wn = 1;   // 4 key digits: 128 accumulator registers + two operand sets spill
     return use ? wn : 0;
 }
 
@@ -1585,13 +1611,14 @@ int qf_launch_gemm(qf_ctx *ctx, const qf_key *key, const void *X, int x_is_bits,
         p.kplanes = key->fold_planes[lb];
         p.ks = key->ks * (uint32_t)lb;
         p.xlb_total = 1; p.xlb_off = 0;
-        if (qf_gemm_shortk_wn(p, la) == 2) {
-            switch (la) {
-                case 1: return qf_gemm_dispatch_shortk<1, 2>(ctx, p);
-                case 2: return qf_gemm_dispatch_shortk<2, 2>(ctx, p);
-                case 3: return qf_gemm_dispatch_shortk<3, 2>(ctx, p);
-                case 4: return qf_gemm_dispatch_shortk<4, 2>(ctx, p);
-            }
+        switch (qf_gemm_shortk_wn(p, la) * 8 + la) {
+            case 2 * 8 + 1: return qf_gemm_dispatch_shortk<1, 2, 1>(ctx, p);
+            case 2 * 8 + 2: return qf_gemm_dispatch_shortk<2, 2, 1>(ctx, p);
+            case 2 * 8 + 3: return qf_gemm_dispatch_shortk<3, 2, 1>(ctx, p);
+            case 2 * 8 + 4: return qf_gemm_dispatch_shortk<4, 2, 1>(ctx, p);
+            case 1 * 8 + 1: return qf_gemm_dispatch_shortk<1, 1, 2>(ctx, p);
+            case 1 * 8 + 2: return qf_gemm_dispatch_shortk<2, 1, 2>(ctx, p);
+            case 1 * 8 + 3: return qf_gemm_dispatch_shortk<3, 1, 2>(ctx, p);
         }
         switch (la) {
             case 1: return qf_gemm_dispatch<1, 1, false>(ctx, p);
