@@ -70,7 +70,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--headline-only", action="store_true", help="do not append the other configurations to the headline line")
     ap.add_argument("--sub-steps", type=int, default=20, help="timed steps of each appended configuration (their steps take 1.6-3 ms)")
-    ap.add_argument("--sub-cpu-seconds", type=float, default=4.0, help="CPU baseline budget of each appended configuration")
+    ap.add_argument("--sub-cpu-seconds", type=float, default=8.0, help="CPU baseline budget of each appended configuration")
     ap.add_argument("--workload", default="regev", choices=WORKLOADS,
                     help="regev = the headline (BASELINE config 2); the others are the remaining configs, "
                          "each printing its own JSON line")
@@ -812,9 +812,9 @@ def workload(R_, wl, args):
                     "ms_per_step": el / args.steps * 1e3, "dtype": "int8",
                     "config": {"workload": "DualRegev enc, secure128 (dual_regev.rs:301-303): c^t = s^t [A|u] + e^t, s uniform in Z_q (3 digits)",
                                "n": n, "m": m, "q": q, "global_batch": Btot, "key_broadcast_ms": bcast["s"] * 1e3},
-                    "roofline": {"kernel": "qf_gemm_kernel<3,3,...> (3x3 digit products, K = n = 230: two k-tiles)", "bound": "hbm",
+                    "roofline": {"kernel": "qf_gemm_shortk_kernel<3,2,1> (3 operand digits folded: K' = 768; key tile resident in LDS, unsynchronised waves)", "bound": "hbm",
                                  "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                 "traffic": pmc_traffic("dualregev", "qf_gemm_kernel") if world == 1 else None, "launch_ms": gemm_ms,
+                                 "traffic": pmc_traffic("dualregev", "qf_gemm_shortk_kernel") if world == 1 else None, "launch_ms": gemm_ms,
                                  "whole_call_ms": ms, "mfma_tops": tops, "mfma_frac": tops / INT8_PEAK_TOPS,
                                  "note": "algorithmic bytes = 4n (s) + 4(m+1) (e) + 4(m+1) (c) = 43,432 per encryption; algorithmic int8 ops = "
                                          "2*3*3*(m+1)*n = 21,999,960 per encryption: 507 op/B, below the 629 op/B balance of the chip"}})

@@ -8,7 +8,7 @@ tag=$1; wl=$2; shift; shift
 out=$PWD/gpurun_out/prof_$tag/$wl
 rm -rf $out; mkdir -p $out
 export TMPDIR=/tmp
-args="--workload $wl --steps 10 --warmup 2 --no-cpu --no-check --headline-only $*"
+args="--workload $wl --steps 40 --warmup 5 --no-cpu --no-check --headline-only $*"
 echo "python3 bench.py $args" > $out/command.txt
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 bench.py $args > $out/bench_trace.json 2> $out/trace.log || { echo "trace pass failed"; tail -5 $out/trace.log; exit 1; }
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o f -- python3 bench.py $args > $out/bench_fetch.json 2> $out/fetch.log || { echo "fetch pass failed"; tail -5 $out/fetch.log; exit 1; }
