@@ -819,8 +819,14 @@ __device__ __forceinline__ void qf_gemm_body(const QfGemmArgs &a, const uint32_t
 // (rows 16*half + (l & 15), k-half (l >> 4) & 1, of k-step 2*s' + (l >> 5)) -- so every lane
 // simply reads a different chunk of the 1-KiB fragment images, and the bits of a message row are
 // expanded per 16-message half.
-template <int LA, int WN, int PK>
+// PL (round 3): the same body for DIGIT-PLANE batch operands (one digit per k-step: LPR's folded r, SIS with Z_q
+// inputs).  The planes stay in the 32x32x32 fragment order the recode kernel writes; as with the key fragments,
+// every lane simply loads a different 16-byte chunk: message row 16*mg + (l & 15), k-half (l >> 4) & 1 of k-step
+// 2*sp + (l >> 5) -- four 16-byte loads per lane and k-tile (two message halves x two k-steps of 64), nothing to
+// expand.  The point is the clock: under v_mfma_i32_32x32x32_i8 the LPR launch ran at 1.67 GHz (power-managed).
+template <int LA, int WN, int PK, bool PL = false>
 __device__ __forceinline__ void qf_gemm_body16(const QfGemmArgs &a, const uint32_t bx, const uint32_t rb_first) {
+    static_assert(!PL || PK == 0, "digit-plane operands: no packed remainder block");
     constexpr bool PACKED = PK != 0;
     constexpr bool PK16 = PK == 2;      // the packed block's r*LA digit rows all lie in its first 16: no second row half
     constexpr int S = LA;                                       // one operand digit
@@ -859,25 +865,49 @@ __device__ __forceinline__ void qf_gemm_body16(const QfGemmArgs &a, const uint32
     // batch operand: the 128 bits per k-tile of message rows 16*mg + lc (inline-asm loads, see QF_LOAD_AT),
     // addressed as (uniform base of the workgroup's first message row) + (32-bit per-lane offset)
     const uint64_t tile_row0 = (uint64_t)bx * QF_NW * 32;
-    const uint8_t *xbase = a.xbits + (tile_row0 < a.B ? tile_row0 : a.B - 1) * a.xstride;
-    uint32_t xoff[2];
+    const uint8_t *xbase = PL ? nullptr : a.xbits + (tile_row0 < a.B ? tile_row0 : a.B - 1) * a.xstride;
+    uint32_t xoff[2] = {0, 0};
+    if constexpr (!PL) {
 #pragma unroll
     for (int mg = 0; mg < 2; mg++) {
         const uint64_t mrow_l = mb0 * 32 + 16 * mg + lc;
         const uint64_t mrow_c = mrow_l < a.B ? mrow_l : a.B - 1;
         xoff[mg] = (uint32_t)((mrow_c - (tile_row0 < a.B ? tile_row0 : a.B - 1)) * a.xstride);   // < 256 rows
     }
+    }
     v4i at[2][2];
+    // digit planes: the wave's message block is ks * xlb_total consecutive KiB; per-lane chunk as described above
+    v4i atp[PL ? 2 : 1][2][2];                         // [set][message half][k-step of 64]
+    const int8_t *pbase = nullptr;
+    uint32_t poff[2] = {0, 0};
+    const uint32_t pstep = a.xlb_total * 1024;         // bytes between consecutive k-steps of a block
+    if constexpr (PL) {
+        const uint64_t nmb = (a.B + 31) / 32;
+        const uint64_t mb_c = mb0 < nmb ? mb0 : nmb - 1;
+        pbase = a.xplanes + ((mb_c * a.ks * a.xlb_total) + a.xlb_off) * 1024;
+#pragma unroll
+        for (int mg = 0; mg < 2; mg++) poff[mg] = (uint32_t)(lq >> 1) * pstep + (uint32_t)((16 * mg + lc) + 32 * (lq & 1)) * 16;
+    }
 #define QF16_LOAD_AT(set_, kt_)                                                                   \
+    if constexpr (PL) {                                                                           \
+        _Pragma("unroll") for (int mg_ = 0; mg_ < 2; mg_++)                                       \
+            _Pragma("unroll") for (int sp_ = 0; sp_ < 2; sp_++)                                   \
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(atp[set_][mg_][sp_])         \
+                             : "v"(poff[mg_] + ((uint32_t)(kt_) * QF_KS + 2 * sp_) * pstep), "s"(pbase) : "memory"); \
+    } else {                                                                                      \
     _Pragma("unroll") for (int mg_ = 0; mg_ < 2; mg_++) {                                         \
         size_t off_ = (size_t)(kt_)*16;                                                           \
         off_ = off_ + 16 <= a.xstride ? off_ : a.xstride - 16;                                    \
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(at[set_][mg_]) : "v"(xoff[mg_] + (uint32_t)off_), "s"(xbase) : "memory"); \
-    }
+    } }
 #define QF16_WAIT_AT(set_, n_)                                                                    \
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory");                                     \
+    if constexpr (PL) {                                                                           \
+        _Pragma("unroll") for (int mg_ = 0; mg_ < 2; mg_++)                                       \
+            _Pragma("unroll") for (int sp_ = 0; sp_ < 2; sp_++) asm volatile("" : "+v"(atp[set_][mg_][sp_])); \
+    } else {                                                                                      \
     asm volatile("" : "+v"(at[set_][0]));                                                         \
-    asm volatile("" : "+v"(at[set_][1]));
+    asm volatile("" : "+v"(at[set_][1])); }
     // 16 bits -> 16 bytes for k-step sp (of 64) of the tile whose words are in at[set_][mg_]: the lane's
     // bits are half (lq & 1) of dword 2*sp + (lq >> 1)
     // the lane's 16 bits of the k-step: word (lq >> 1) of the step's two, half (lq & 1) of it.  The two
@@ -922,15 +952,18 @@ __device__ __forceinline__ void qf_gemm_body16(const QfGemmArgs &a, const uint32
     const uint32_t halfsh = (uint32_t)(lq & 1) * 16;
 #pragma unroll
     for (int g = 0; g < D; g++) QF16_RD(g, laneA, laneP, g)
+    if constexpr (!PL) {
 #pragma unroll
     for (int mg = 0; mg < 2; mg++) {
         QF16_WSEL(0, mg, 0)
 #pragma unroll
         for (int d = 0; d < 4; d++) QF16_EXPAND(afb[0][mg], mg, d)
     }
+    }
     __builtin_amdgcn_sched_barrier(0);
     // group of the tile's second k-step behind which the next tile's bits are waited for and expanded
-    constexpr int WPOS = H + NBF < G ? H + NBF : G - 1;
+    // (digit planes: nothing to expand, the wait sits in front of the tile's last group)
+    constexpr int WPOS = PL ? G - 1 : (H + NBF < G ? H + NBF : G - 1);
     constexpr bool SPREAD = (WPOS - H) + 10 <= H;   // one expansion piece per group (10 pieces per k-step of 64), else all at once
     uint32_t buf = 0;
     for (uint32_t kt = 0; kt < ntiles; kt++) {
@@ -965,13 +998,13 @@ __device__ __forceinline__ void qf_gemm_body16(const QfGemmArgs &a, const uint32
             const int l = (PACKED && fi == NBF - 1) ? 0 : fi % LA;
 #pragma unroll
             for (int mg = 0; mg < 2; mg++)
-                acc[mg][j][kg][l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afb[sp][mg], ring[slot], acc[mg][j][kg][l], 0, 0, 0);
+                acc[mg][j][kg][l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(PL ? atp[0][mg][sp] : afb[sp][mg], ring[slot], acc[mg][j][kg][l], 0, 0, 0);
             const int gn = g + D;
             if (gn < G) { QF16_RD(slot, tA, tP, gn) }
             else { QF16_RD(slot, laneA + buf1 * TILE_BYTES, laneP + buf1 * TILE_BYTES, gn - G) }   // the next tile's first chunks
             // the operand of the NEXT k-step of 64 (sp = 0: this tile's second; sp = 1, behind the counted
             // wait: the next tile's first): per message half one word select + four dword expansions
-            {
+            if constexpr (!PL) {
                 const int e0 = sp == 0 ? 0 : WPOS - H;
 #pragma unroll
                 for (int mg = 0; mg < 2; mg++) {
@@ -990,8 +1023,15 @@ __device__ __forceinline__ void qf_gemm_body16(const QfGemmArgs &a, const uint32
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (PL) {
+#pragma unroll
+            for (int mg = 0; mg < 2; mg++)
+#pragma unroll
+                for (int sp = 0; sp < 2; sp++) atp[0][mg][sp] = atp[1][mg][sp];
+        } else {
         at[0][0] = at[1][0];
         at[0][1] = at[1][1];
+        }
         buf = buf1;
     }
     // the reads issued for a tile past the end must not land in registers the epilogue re-uses
@@ -1017,6 +1057,34 @@ __device__ __forceinline__ void qf_gemm_body16(const QfGemmArgs &a, const uint32
     const uint32_t mlim = mleft > 32 ? 32u : (uint32_t)mleft;     // messages of this wave's block inside the batch
 #pragma unroll
     for (int mg = 0; mg < 2; mg++) {
+    // Addend words of the whole message half -- WN blocks x 8 per lane -- requested together, ahead of the first
+    // block's arithmetic (digit-plane operands; 8 at a time left the LPR epilogue 0.1 ms behind the
+    // 32x32x32 body's 16 at a time).  A descriptor with 0 records returns zeros without touching memory.
+    constexpr bool PRE = PL && WN * LA * 16 + WN * 8 <= 216;   // tiles of 192 accumulator registers + 32 words: no room, 8 at a time
+    uint32_t addall[PRE ? WN : 1][2][4];
+    if constexpr (PRE) {
+        if (a.addend) {
+#pragma unroll
+            for (int j = 0; j < WN; j++) {
+                const bool live = rb0 + j < a.rb;
+                const uint64_t col0 = live ? (uint64_t)(rb0 + j) * 32 : 0;
+                const auto rs_a = __builtin_amdgcn_make_buffer_rsrc((void *)(a.addend + mb0 * 32 * a.rows + col0), 0,
+                                                                    live ? (int)(mlim * rowbytes - (uint32_t)col0 * 4) : 0, 0x00020000);
+#pragma unroll
+                for (int kg = 0; kg < 2; kg++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        addall[j][kg][r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_a, (int)(voff + (16 * mg + r) * rowbytes) + 64 * kg, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < WN; j++)
+#pragma unroll
+                for (int kg = 0; kg < 2; kg++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) addall[j][kg][r] = 0;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < WN; j++) {
         if (PACKED && j == WN - 1) {
@@ -1073,6 +1141,17 @@ __device__ __forceinline__ void qf_gemm_body16(const QfGemmArgs &a, const uint32
             }
             continue;
         }
+        // the block's 8 addend words per lane are requested together (one at a time, each load was waited for on its
+        // own: LPR 2.18 -> 2.51 ms when the digit-plane path first came through this epilogue); a descriptor with 0
+        // records (no addend) returns zeros without touching memory
+        uint32_t addw[2][4];
+#pragma unroll
+        for (int kg = 0; kg < 2; kg++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if constexpr (!PRE) addw[kg][r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_add, (int)(voff + (16 * mg + r) * rowbytes) + 64 * kg, 0, 0);
+                else addw[kg][r] = addall[j][kg][r];
+            }
 #pragma unroll
         for (int kg = 0; kg < 2; kg++) {
             const uint32_t krow = (rb0 + j) * 32 + 16 * kg + lc;
@@ -1080,8 +1159,7 @@ __device__ __forceinline__ void qf_gemm_body16(const QfGemmArgs &a, const uint32
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int vo = (int)(voff + (16 * mg + r) * rowbytes) + 64 * kg;
-                double extra = 0.0;
-                if (a.addend) extra = (double)(uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_add, vo, 0, 0);
+                double extra = (double)addw[kg][r];
                 if (has_last) {   // uniform: only the row block that holds the last key row
                     asm volatile("");
                     if (krow == lastrow && ((msgmask >> (16 * mg + 4 * lq + r)) & 1)) extra += (double)a.mod.qhalf;
@@ -1121,6 +1199,10 @@ __global__ __launch_bounds__(QF_NW * 64, (MW * WN * (LA + LB - 1) * 16 + (BITS ?
 #ifndef QF_GEMM_MFMA32
     if constexpr (BITS && MW == 1 && LB == 1) qf_gemm_body16<LA, WN, 0>(a, bx, by * WN);
     else
+#ifndef QF_GEMM_PLANES32
+    if constexpr (!BITS && MW == 1 && LB == 1) qf_gemm_body16<LA, WN, 0, true>(a, bx, by * WN);
+    else
+#endif
 #endif
     qf_gemm_body<LA, LB, WN, MW, BITS, false>(a, bx, by * WN);
 }
