@@ -29,6 +29,9 @@
 #include "qf_internal.h"
 
 #define QF_NW 8          // waves per workgroup
+#ifndef QF_PL_D4
+#define QF_PL_D4 0
+#endif
 #ifndef QF_EPI_AUX_LD
 #define QF_EPI_AUX_LD 0  // cache policy of the epilogue's addend loads (2 = nt)
 #endif
@@ -837,7 +840,7 @@ __device__ __forceinline__ void qf_gemm_body16(const QfGemmArgs &a, const uint32
     constexpr int H = 2 * NBF - (PK16 ? 1 : 0);                 // groups per k-step of 64: NBF fragments x 2 row halves
     constexpr int G = 2 * H;                                    // groups (= LDS reads) per k-tile
     constexpr int ACCREGS = (PACKED ? (WN - 1) * S * 16 + (PK16 ? 8 : 16) : WN * S * 16);
-    constexpr int D0 = (NBF >= 2 && ACCREGS < 192 && !PK16) ? 4 : 2;   // chunks in flight (ring registers / 4)
+    constexpr int D0 = (NBF >= 2 && (ACCREGS < 192 || (PL && QF_PL_D4)) && !PK16) ? 4 : 2;   // chunks in flight (ring registers / 4)
     constexpr int D = D0 <= G / 2 ? D0 : G / 2;
     static_assert(G % D == 0 && D <= G / 2, "ring slots repeat per tile; reads must not pass the mid-tile barrier");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 3 * TILE_BYTES
