@@ -48,6 +48,16 @@ def test_regev_config2(ctx, n, m, q, B):
     rows = _rows(B)
     ref = co.matmul_batch(ctx.to_host_u32(pk), q, ctx.to_host_u8(x[rows]), co.X_BITS, len(rows), msg=ctx.to_host_u8(msg[rows]), mt=True)
     assert np.array_equal(ctx.to_host_u32(c[rows]), ref)
+    # a batch that ends inside a message tile (B mod 256 = 93, mod 32 = 29) at the full K: every row of the partial last tile
+    # against the oracle, the rest against the full batch, nothing written behind the batch
+    Bp = 256 * 17 + 93
+    guard = ctx.empty_u32(Bp + 1, n + 1)
+    guard.fill_(-1)
+    cp = ctx.matmul(key, x[:Bp], X_BITS, Bp, msg=msg[:Bp], out=guard[:Bp])
+    assert torch.equal(cp, c[:Bp]) and bool((guard[Bp] == -1).all())
+    last = np.arange(256 * 17, Bp)
+    ref = co.matmul_batch(ctx.to_host_u32(pk), q, ctx.to_host_u8(x[last]), co.X_BITS, len(last), msg=ctx.to_host_u8(msg[last]), mt=True)
+    assert np.array_equal(ctx.to_host_u32(cp[last]), ref)
 
 
 @pytest.mark.timeout(300)
@@ -112,6 +122,17 @@ def test_lpr_config4(ctx):
     ref = co.matmul_batch(ctx.to_host_u32(pk), q, ctx.to_host_u32(r[rows]), co.X_U32, len(rows), addend=ctx.to_host_u32(e[rows]),
                           msg=ctx.to_host_u8(msg[rows]), mt=True)
     assert np.array_equal(ctx.to_host_u32(c[rows]), ref)
+    # a batch that ends inside a message tile at the full K (digit-plane operands on the 16x16x64 body): the rows of the
+    # partial last tile against the oracle, the rest against the full batch, nothing written behind the batch
+    Bp = 256 * 9 + 93
+    guard = ctx.empty_u32(Bp + 1, n + 1)
+    guard.fill_(-1)
+    cp = ctx.matmul(key, r[:Bp], X_U32, Bp, addend=e[:Bp], msg=msg[:Bp], x_digits=2, out=guard[:Bp])
+    assert torch.equal(cp, c[:Bp]) and bool((guard[Bp] == -1).all())
+    last = np.arange(256 * 9 + 60, Bp)
+    ref = co.matmul_batch(ctx.to_host_u32(pk), q, ctx.to_host_u32(r[last]), co.X_U32, len(last), addend=ctx.to_host_u32(e[last]),
+                          msg=ctx.to_host_u8(msg[last]), mt=True)
+    assert np.array_equal(ctx.to_host_u32(cp[last]), ref)
 
 
 @pytest.mark.timeout(400)
