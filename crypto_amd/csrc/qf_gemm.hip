@@ -1058,38 +1058,39 @@ __device__ __forceinline__ void qf_gemm_body16(const QfGemmArgs &a, const uint32
     const int64_t mleft = (int64_t)a.B - (int64_t)(mb0 * 32);
     if (mleft <= 0) return;                                       // uniform; nothing after the epilogue
     const uint32_t mlim = mleft > 32 ? 32u : (uint32_t)mleft;     // messages of this wave's block inside the batch
+    // Addend words of a whole message half -- WN blocks x 8 per lane -- requested together, ahead of the half's
+    // arithmetic (digit-plane operands; 8 at a time left the LPR epilogue 0.1 ms behind the 32x32x32 body's 16 at a
+    // time).  The second half's words are requested as soon as the first half's first row block is done and its
+    // accumulator registers are free (>= 8 LA per block against 8 WN words), so their latency runs under the
+    // rest of the first half.  A descriptor with 0 records returns zeros without touching memory.
+    constexpr bool PRE = PL && WN * LA * 16 + WN * 8 <= 216;   // tiles of 192 accumulator registers + 32 words: no room, 8 at a time
+    uint32_t addall[PRE ? 2 : 1][PRE ? WN : 1][2][4];
+#define QF16_ADD_HALF(MG_)                                                                                                \
+    if constexpr (PRE) {                                                                                                  \
+        if (a.addend) {                                                                                                   \
+            _Pragma("unroll") for (int j_ = 0; j_ < WN; j_++) {                                                           \
+                const bool live_ = rb0 + j_ < a.rb;                                                                       \
+                const uint64_t c0_ = live_ ? (uint64_t)(rb0 + j_) * 32 : 0;                                               \
+                const auto rs_a = __builtin_amdgcn_make_buffer_rsrc((void *)(a.addend + mb0 * 32 * a.rows + c0_), 0,      \
+                                                                    live_ ? (int)(mlim * rowbytes - (uint32_t)c0_ * 4) : 0, 0x00020000); \
+                _Pragma("unroll") for (int kg_ = 0; kg_ < 2; kg_++)                                                       \
+                    _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++)                                                      \
+                        addall[PRE ? (MG_) : 0][PRE ? j_ : 0][kg_][r_] =                                                  \
+                            (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_a, (int)(voff + (16 * (MG_) + r_) * rowbytes) + 64 * kg_, 0, 0); \
+            }                                                                                                             \
+        } else {                                                                                                          \
+            _Pragma("unroll") for (int j_ = 0; j_ < WN; j_++)                                                             \
+                _Pragma("unroll") for (int kg_ = 0; kg_ < 2; kg_++)                                                       \
+                    _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++) addall[PRE ? (MG_) : 0][PRE ? j_ : 0][kg_][r_] = 0;  \
+        }                                                                                                                 \
+    }
+    QF16_ADD_HALF(0)
+    if constexpr (WN == 1) { QF16_ADD_HALF(1) }
 #pragma unroll
     for (int mg = 0; mg < 2; mg++) {
-    // Addend words of the whole message half -- WN blocks x 8 per lane -- requested together, ahead of the first
-    // block's arithmetic (digit-plane operands; 8 at a time left the LPR epilogue 0.1 ms behind the
-    // 32x32x32 body's 16 at a time).  A descriptor with 0 records returns zeros without touching memory.
-    constexpr bool PRE = PL && WN * LA * 16 + WN * 8 <= 216;   // tiles of 192 accumulator registers + 32 words: no room, 8 at a time
-    uint32_t addall[PRE ? WN : 1][2][4];
-    if constexpr (PRE) {
-        if (a.addend) {
-#pragma unroll
-            for (int j = 0; j < WN; j++) {
-                const bool live = rb0 + j < a.rb;
-                const uint64_t col0 = live ? (uint64_t)(rb0 + j) * 32 : 0;
-                const auto rs_a = __builtin_amdgcn_make_buffer_rsrc((void *)(a.addend + mb0 * 32 * a.rows + col0), 0,
-                                                                    live ? (int)(mlim * rowbytes - (uint32_t)col0 * 4) : 0, 0x00020000);
-#pragma unroll
-                for (int kg = 0; kg < 2; kg++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        addall[j][kg][r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_a, (int)(voff + (16 * mg + r) * rowbytes) + 64 * kg, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < WN; j++)
-#pragma unroll
-                for (int kg = 0; kg < 2; kg++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) addall[j][kg][r] = 0;
-        }
-    }
 #pragma unroll
     for (int j = 0; j < WN; j++) {
+        if constexpr (WN > 1) { if (mg == 0 && j == 1) { QF16_ADD_HALF(1) } }
         if (PACKED && j == WN - 1) {
             // remainder block: fragment row p = i*LA + l holds digit l of trailing row i, i.e. it sits in row
             // half p >> 4 at lane column p & 15 (same message quarter).  Lane column c serves trailing rows
@@ -1153,7 +1154,7 @@ __device__ __forceinline__ void qf_gemm_body16(const QfGemmArgs &a, const uint32
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 if constexpr (!PRE) addw[kg][r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_add, (int)(voff + (16 * mg + r) * rowbytes) + 64 * kg, 0, 0);
-                else addw[kg][r] = addall[j][kg][r];
+                else addw[kg][r] = addall[PRE ? mg : 0][PRE ? j : 0][kg][r];
             }
 #pragma unroll
         for (int kg = 0; kg < 2; kg++) {
