@@ -23,6 +23,16 @@ if "regev" in which:
     msg = ctx.sample_bits(1, 5, 0, 1, B).view(-1)[: B // 8]
     out = ctx.empty_u32(B, n + 1)
     res.append("regev %.4f ms" % timeit(lambda: ctx.matmul(key, xb, X_BITS, B, out=out)))
+if "regevcold" in which:   # six rotating operand / output sets (6 x 118 MB > the Infinity Cache), as bench.py's headline
+    n, m, q, B = 256, 6168, 16777213, 65536
+    key = ctx.key_upload(ctx.sample_uniform(1, 1, 0, (n + 1) * m, q).view(n + 1, m), q)
+    xs = [ctx.sample_bits(1, 3, i, B, m) for i in range(6)]
+    outs = [ctx.empty_u32(B, n + 1) for i in range(6)]
+    it = {"i": 0}
+    def step():
+        i = it["i"] = (it["i"] + 1) % 6
+        ctx.matmul(key, xs[i], X_BITS, B, out=outs[i])
+    res.append("regev(cold) %.4f ms" % timeit(step, 60))
 if "sis" in which:
     n, q = 512, 8380417
     m, B = n * 23, 1 << 18
