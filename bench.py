@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--no-check", action="store_true", help="skip the small property-check launches (profile runs: keeps "
                                                              "the kernel-trace averages to full-size launches only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--bits-layout", choices=["kt", "rows"], default="kt",
+                    help="resident form of the bit operands (Regev x, SIS inputs): k-tile-major planes (QF_X_BITS_KT) or row-major rows")
     ap.add_argument("--headline-only", action="store_true", help="do not append the other configurations to the headline line")
     ap.add_argument("--sub-steps", type=int, default=20, help="timed steps of each appended configuration (their steps take 1.6-3 ms)")
     ap.add_argument("--sub-cpu-seconds", type=float, default=8.0, help="CPU baseline budget of each appended configuration")
@@ -320,7 +322,7 @@ def headline(args):
     import numpy as np
     R_ = Run(args)
     torch, ctx, rank, world = R_.torch, R_.ctx, R_.rank, R_.world
-    from crypto_amd.device import X_BITS
+    from crypto_amd.device import X_BITS, X_BITS_KT
 
     n, m, q = 256, 6168, 16777213
     B, NS = args.batch, max(2, args.sets)
@@ -351,18 +353,24 @@ def headline(args):
         sets.append({"x": ctx.sample_bits(SEED, 3, first, B, m),
                      "msg": (ctx.sample_uniform(SEED, 5, first, B, 2) & 1).to(torch.uint8),
                      "c": ctx.empty_u32(B, n + 1), "bits": ctx.empty_u8(B)})
+        # the resident batch operand of the timed region: the same bits k-tile-major (QF_X_BITS_KT; layout of our boundary --
+        # the reference has no packed form of x).  --bits-layout rows keeps the row-major rows.
+        sets[i]["xk"] = ctx.bits_to_kt(sets[i]["x"], B, m) if args.bits_layout == "kt" else None
     state = {"k": 0}
 
-    def enc(i):
-        ctx.matmul(key, sets[i]["x"], X_BITS, B, msg=sets[i]["msg"], out=sets[i]["c"])
+    def enc(i, rows=False):
+        if rows or args.bits_layout != "kt":
+            ctx.matmul(key, sets[i]["x"], X_BITS, B, msg=sets[i]["msg"], out=sets[i]["c"])
+        else:
+            ctx.matmul(key, sets[i]["xk"], X_BITS_KT, B, msg=sets[i]["msg"], out=sets[i]["c"])
 
     def dec(i):
         ctx.dot_decode(w, q, sets[i]["c"], out=sets[i]["bits"])
 
-    def step():
+    def step(rows=False):
         i = state["k"] % NS
         state["k"] += 1
-        enc(i)                    # encrypt set i ...
+        enc(i, rows)              # encrypt set i ...
         dec((i + 1) % NS)         # ... decrypt the set encrypted NS-1 steps ago (HBM-cold)
 
     def check_round_trip():
@@ -397,8 +405,13 @@ def headline(args):
     def step_sampling():
         i = state["k"] % NS
         draw["k"] += 1
-        ctx.sample_bits(SEED, 3, ((world + rank) * NS + draw["k"]) * B, B, m, out=sets[i]["x"])
-        step()
+        first = ((world + rank) * NS + draw["k"]) * B
+        if args.bits_layout == "kt":
+            ctx.sample_bits_kt(SEED, 3, first, B, m, out=sets[i]["xk"])   # the sampler writes the planes itself
+            step()
+        else:
+            ctx.sample_bits(SEED, 3, first, B, m, out=sets[i]["x"])
+            step(rows=True)
     k2 = max(5, args.steps // 2)
     el2, _ = R_.timed(step_sampling, k2, 2)
     check_round_trip()
@@ -411,7 +424,8 @@ def headline(args):
         "data": "synthetic (seeded SplitMix64 on device)",
         "config": {"workload": "Regev enc+dec round trip (BASELINE config 2)", "n": n, "m": m, "q": q,
                    "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"batch-shard x{world}",
-                   "buffer_sets": NS, "key_broadcast_ms": t_bcast * 1e3},
+                   "buffer_sets": NS, "key_broadcast_ms": t_bcast * 1e3,
+                   "bits_layout": "k-tile-major (QF_X_BITS_KT)" if args.bits_layout == "kt" else "row-major (QF_X_BITS)"},
         "ms_per_step_events": region_ms / args.steps, "event_pair_overhead_ms": pair_ms,
         "roofline": {"kernel": "qf_gemm_packedx_kernel<3,4> (bit operands on v_mfma_i32_16x16x64_i8; two column tiles of 4 row blocks, the packed remainder block as a 13th fragment of the last)", "bound": "mfma",
                      "achieved": achieved_tops, "peak": INT8_PEAK_TOPS, "unit": "TOP/s", "frac": achieved_tops / INT8_PEAK_TOPS,
@@ -454,6 +468,8 @@ def headline(args):
         probe = 64
         xs, ms_, cs = sets[0]["x"], sets[0]["msg"], sets[0]["c"]
         ctx.sample_bits(SEED, 3, (rank * NS) * B, B, m, out=xs)    # set 0 as first generated
+        if args.bits_layout == "kt":
+            ctx.bits_to_kt(xs, B, m, out=sets[0]["xk"])
         enc(0)
         xb_h = ctx.to_host_u8(xs[:probe])
         t1 = time.perf_counter()
@@ -538,15 +554,21 @@ def workload(R_, wl, args):
         A = replicated(n * m, q, (n, m))
         key = ctx.key_upload(A, q)
         xb = ctx.sample_bits(SEED, 3, lo, B, m)
+        xk = ctx.bits_to_kt(xb, B, m) if args.bits_layout == "kt" else None
         dig = ctx.empty_u32(B, n)
-        el, ems = R_.timed(lambda: ctx.matmul(key, xb, X_BITS, B, out=dig), args.steps, args.warmup)
+        if xk is not None:
+            from crypto_amd.device import X_BITS_KT
+            el, ems = R_.timed(lambda: ctx.matmul(key, xk, X_BITS_KT, B, out=dig), args.steps, args.warmup)
+        else:
+            el, ems = R_.timed(lambda: ctx.matmul(key, xb, X_BITS, B, out=dig), args.steps, args.warmup)
         ms = ems / args.steps
         ops = 2 * 3 * n * m
         tops = ops * B / (ms * 1e-3) / 1e12
         out.update({"metric": "SIS hashes/sec", "value": Btot * args.steps / el, "unit": "hashes/s", "scaling": "strong",
                     "ms_per_step": el / args.steps * 1e3, "dtype": "int8",
                     "config": {"workload": "SIS hash, binary inputs (BASELINE config 3)", "n": n, "m": m, "q": q, "global_batch": Btot,
-                               "key_broadcast_ms": bcast["s"] * 1e3},
+                               "key_broadcast_ms": bcast["s"] * 1e3,
+                               "bits_layout": "k-tile-major (QF_X_BITS_KT)" if xk is not None else "row-major (QF_X_BITS)"},
                     "roofline": {"kernel": "qf_gemm_kernel<3,1,4,1,bits> (v_mfma_i32_16x16x64_i8)", "bound": "mfma", "achieved": tops, "peak": INT8_PEAK_TOPS,
                                  "unit": "TOP/s", "frac": tops / INT8_PEAK_TOPS, "traffic": pmc_traffic("sis", "qf_gemm_kernel<3, 1, 4, 1, true>") if world == 1 else None,
                                  "launch_ms": ms, "note": "algorithmic int8 ops = 2*3*n*m per hash x B per launch; one launch per step"}})

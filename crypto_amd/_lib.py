@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QF_LIB_PATH") or os.path.join(_HERE, "lib", "libqfgpu.so")  # override: diagnostic builds only
 
 QF_OK, QF_ERR_ARG, QF_ERR_DIM, QF_ERR_MODULUS, QF_ERR_DEVICE, QF_ERR_RANGE, QF_ERR_NOTSUP = range(7)
-X_BITS, X_U32, X_I32 = 0, 1, 2
+X_BITS, X_U32, X_I32, X_BITS_KT = 0, 1, 2, 3
 
 _ERR_NAMES = {1: "QF_ERR_ARG", 2: "QF_ERR_DIM", 3: "QF_ERR_MODULUS", 4: "QF_ERR_DEVICE",
               5: "QF_ERR_RANGE", 6: "QF_ERR_NOTSUP"}
@@ -48,6 +48,7 @@ SYMBOLS = {
     "qf_key_u32_dev": (_i, [_vp, _pp, C.POINTER(_sz)]),
     "qf_key_replicate": (_i, [_pp, _i, _vp, _pp]),
     "qf_matmul_modq_dev": (_i, [_vp, _vp, _vp, _i, _sz, _i, _u64, _vp, _vp, _vp]),
+    "qf_bits_to_kt_dev": (_i, [_vp, _vp, _sz, _u64, _u32, _vp, _sz]),
     "qf_matvec_modq_host": (_i, [_vp, _vp, _vp, _vp]),
     "qf_vecmat_modq_host": (_i, [_vp, _vp, _vp, _vp]),
     "qf_matvec_modq_dev": (_i, [_vp, _vp, _vp, _vp]),
@@ -68,10 +69,12 @@ SYMBOLS = {
     "qf_fdh_ring_verify_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _vp]),
     "qf_sample_uniform_dev": (_i, [_vp, _u64, _u32, _u64, _u64, _u32, _vp]),
     "qf_sample_bits_dev": (_i, [_vp, _u64, _u32, _u64, _u64, _u32, _u32, _vp]),
+    "qf_sample_bits_kt_dev": (_i, [_vp, _u64, _u32, _u64, _u64, _u32, _sz, _vp]),
     "qf_sample_noise_dev": (_i, [_vp, _u64, _u32, _u64, _u64, _u32, _u32, _vp]),
     "qf_sample_discrete_gauss_dev": (_i, [_vp, _u64, _u32, _u64, _u64, _u32, _u32, C.c_double, _vp]),
     "qf_sample_uniform_keyed_dev": (_i, [_vp, C.c_char_p, _u64, _u32, _u64, _u64, _u32, _vp]),
     "qf_sample_bits_keyed_dev": (_i, [_vp, C.c_char_p, _u64, _u32, _u64, _u64, _u32, _u32, _vp]),
+    "qf_sample_bits_kt_keyed_dev": (_i, [_vp, C.c_char_p, _u64, _u32, _u64, _u64, _u32, _sz, _vp]),
     "qf_sample_noise_keyed_dev": (_i, [_vp, C.c_char_p, _u64, _u32, _u64, _u64, _u32, _u32, _vp]),
     "qf_sample_discrete_gauss_keyed_dev": (_i, [_vp, C.c_char_p, _u64, _u32, _u64, _u64, _u32, _u32, C.c_double, _vp]),
     "qf_set_timing": (_i, [_vp, _i]),

@@ -12,7 +12,7 @@ from fractions import Fraction
 
 import numpy as np
 
-from ...device import X_BITS, bit_stride, pack_bits
+from ...device import X_BITS, X_BITS_KT, bit_stride, pack_bits
 from ...math import MatZq, MathError, as_fraction, gaussian_width, log2_ceil
 from ._matrix_scheme import MatrixSchemeMixin, message_bit
 from .base import GenericMultiBitEncryption, largest_prime_at_most
@@ -114,8 +114,10 @@ class Regev(MatrixSchemeMixin, GenericMultiBitEncryption):
         msg = np.array([message_bit(v) for v in np.asarray(messages).reshape(-1)], np.uint8)
         B = msg.size
         if x_bits is None:
+            # x drawn here (regev.rs:401): the same bits as sample_bits, written k-tile-major -- the form kernel (a) reads fastest
             first = self.rng._take(3, B)
-            x_bits = ctx.sample_bits(self.rng.seed, 3, first, B, self.m)
+            x_kt = ctx.sample_bits_kt(self.rng.seed, 3, first, B, self.m)
+            return ctx.matmul(self._dev_key(pk), x_kt, X_BITS_KT, B, msg=ctx.to_dev_u8(msg))
         elif isinstance(x_bits, np.ndarray):
             x_bits = ctx.to_dev_u8(x_bits if x_bits.shape[1] == bit_stride(self.m) else pack_bits(x_bits))
         return ctx.matmul(self._dev_key(pk), x_bits, X_BITS, B, msg=ctx.to_dev_u8(msg))

@@ -336,6 +336,44 @@ int qf_key_u32_dev(const qf_key *key, const uint32_t **dev_ptr, size_t *bytes) {
     return QF_OK;
 }
 
+// ------------------------------------------------------------------ bit rows -> k-tile-major planes
+// One workgroup moves 64 rows x 8 k-tiles (one 128-byte line per row): read 8 threads per row, written 64 rows per
+// k-tile (1 KiB runs), the transposition goes through LDS.
+__global__ __launch_bounds__(512) void qf_bits_to_kt_kernel(const uint8_t *__restrict__ in, size_t stride, uint64_t B, uint32_t ntiles,
+                                                             uint8_t *__restrict__ out, size_t kt_stride) {
+    __shared__ uint4 tile[8][65];
+    const uint64_t b0 = (uint64_t)blockIdx.x * 64;
+    const uint32_t t0 = blockIdx.y * 8;
+    {
+        const uint32_t r = threadIdx.x >> 3, tt = threadIdx.x & 7;
+        uint4 v = {0, 0, 0, 0};
+        if (b0 + r < B && t0 + tt < ntiles && (size_t)(t0 + tt) * 16 + 16 <= stride)
+            v = *(const uint4 *)(in + (b0 + r) * stride + (size_t)(t0 + tt) * 16);
+        tile[tt][r] = v;
+    }
+    __syncthreads();
+    const uint32_t tt = threadIdx.x >> 6, r = threadIdx.x & 63;
+    if (b0 + r < B && t0 + tt < ntiles) *(uint4 *)(out + (size_t)(t0 + tt) * kt_stride + (b0 + r) * 16) = tile[tt][r];
+}
+int qf_bits_to_kt_dev(qf_ctx *ctx, const uint8_t *bits_dev, size_t stride_bytes, uint64_t B, uint32_t cols,
+                      uint8_t *kt_dev, size_t kt_stride_bytes) {
+    if (!ctx) return QF_ERR_ARG;
+    if (B == 0 || cols == 0) return QF_OK;
+    if (!bits_dev || !kt_dev) return qf_fail(ctx, QF_ERR_ARG, "bits_to_kt: null operand");
+    if (stride_bytes % 16 || kt_stride_bytes % 16 || ((uintptr_t)bits_dev & 15) || ((uintptr_t)kt_dev & 15))
+        return qf_fail(ctx, QF_ERR_ARG, "bits_to_kt: rows and planes must be 16-byte aligned/strided");
+    if (stride_bytes * 8 < cols) return qf_fail(ctx, QF_ERR_DIM, "bits_to_kt: bit rows shorter than cols");
+    if (kt_stride_bytes / 16 < B) return qf_fail(ctx, QF_ERR_DIM, "bits_to_kt: planes shorter than the batch");
+    const uint32_t ntiles = (cols + 127) / 128;
+    const uint64_t bx = (B + 63) / 64;
+    if (bx > 0x7fffffffull) return qf_fail(ctx, QF_ERR_NOTSUP, "bits_to_kt: batch too large");
+    QF_BIND(ctx);
+    hipLaunchKernelGGL(qf_bits_to_kt_kernel, dim3((unsigned)bx, (ntiles + 7) / 8), dim3(512), 0, ctx->stream, bits_dev, stride_bytes, B,
+                       ntiles, kt_dev, kt_stride_bytes);
+    QF_HIP(ctx, hipGetLastError());
+    return QF_OK;
+}
+
 // ------------------------------------------------------------------ kernel (a)
 int qf_matmul_modq_dev(qf_ctx *ctx, const qf_key *key, const void *X_dev, int x_kind, size_t x_stride_bytes,
                        int x_digits, uint64_t B, const uint32_t *addend_dev, const uint8_t *msg_dev,
@@ -349,6 +387,12 @@ int qf_matmul_modq_dev(qf_ctx *ctx, const qf_key *key, const void *X_dev, int x_
         if (x_stride_bytes % 16 || ((uintptr_t)X_dev & 15)) return qf_fail(ctx, QF_ERR_ARG, "matmul: bit rows must be 16-byte aligned/strided");
         if (x_stride_bytes * 8 < key->cols) return qf_fail(ctx, QF_ERR_DIM, "matmul: bit rows shorter than the key's column count");
         return qf_launch_gemm(ctx, key, X_dev, 1, x_stride_bytes, 1, B, addend_dev, msg_dev, out_dev);
+    }
+    if (x_kind == QF_X_BITS_KT) {
+        // x_stride_bytes = distance between the planes of two k-tiles; ceil(cols / 128) planes of B 16-byte words
+        if (x_stride_bytes % 16 || ((uintptr_t)X_dev & 15)) return qf_fail(ctx, QF_ERR_ARG, "matmul: k-tile planes must be 16-byte aligned/strided");
+        if (x_stride_bytes / 16 < B) return qf_fail(ctx, QF_ERR_DIM, "matmul: k-tile planes shorter than the batch");
+        return qf_launch_gemm(ctx, key, X_dev, 2, x_stride_bytes, 1, B, addend_dev, msg_dev, out_dev);
     }
     if (x_kind != QF_X_U32 && x_kind != QF_X_I32) return qf_fail(ctx, QF_ERR_ARG, "matmul: unknown operand kind");
     if (x_stride_bytes < (size_t)key->cols * 4 || x_stride_bytes % 4) return qf_fail(ctx, QF_ERR_DIM, "matmul: operand rows shorter than the key's column count");
@@ -652,6 +696,14 @@ static int sample_bits(qf_ctx *ctx, const QfGen &g, uint64_t first_row, uint64_t
     QF_BIND(ctx);
     return qf_launch_sample_bits(ctx, g, first_row, rows, cols, stride_bytes, out_dev);
 }
+static int sample_bits_kt(qf_ctx *ctx, const QfGen &g, uint64_t first_row, uint64_t rows, uint32_t cols, size_t kt_stride_bytes, uint8_t *out_dev) {
+    if (!ctx || (!out_dev && rows && cols)) return QF_ERR_ARG;
+    if (kt_stride_bytes % 16 || ((uintptr_t)out_dev & 15)) return qf_fail(ctx, QF_ERR_ARG, "sample bits (k-tile-major): planes must be 16-byte aligned/strided");
+    if (kt_stride_bytes / 16 < rows) return qf_fail(ctx, QF_ERR_DIM, "sample bits (k-tile-major): planes shorter than the rows");
+    if ((cols + 127) / 128 > 65535) return qf_fail(ctx, QF_ERR_NOTSUP, "sample bits (k-tile-major): too many columns");
+    QF_BIND(ctx);
+    return qf_launch_sample_bits_kt(ctx, g, first_row, rows, cols, kt_stride_bytes, out_dev);
+}
 static int sample_noise(qf_ctx *ctx, const QfGen &g, uint64_t first, uint64_t count, uint32_t q, uint32_t W, uint32_t *out_dev) {
     if (!ctx || (!out_dev && count)) return QF_ERR_ARG;
     int rc = check_q(ctx, q);
@@ -667,6 +719,10 @@ int qf_sample_bits_dev(qf_ctx *ctx, uint64_t seed, uint32_t stream, uint64_t fir
                        uint32_t stride_bytes, uint8_t *out_dev) {
     return sample_bits(ctx, gen_seeded(seed, stream), first_row, rows, cols, stride_bytes, out_dev);
 }
+int qf_sample_bits_kt_dev(qf_ctx *ctx, uint64_t seed, uint32_t stream, uint64_t first_row, uint64_t rows, uint32_t cols,
+                          size_t kt_stride_bytes, uint8_t *out_dev) {
+    return sample_bits_kt(ctx, gen_seeded(seed, stream), first_row, rows, cols, kt_stride_bytes, out_dev);
+}
 int qf_sample_noise_dev(qf_ctx *ctx, uint64_t seed, uint32_t stream, uint64_t first, uint64_t count, uint32_t q, uint32_t W, uint32_t *out_dev) {
     return sample_noise(ctx, gen_seeded(seed, stream), first, count, q, W, out_dev);
 }
@@ -679,6 +735,11 @@ int qf_sample_bits_keyed_dev(qf_ctx *ctx, const uint8_t *key32, uint64_t nonce, 
                              uint32_t cols, uint32_t stride_bytes, uint8_t *out_dev) {
     if (!key32) return QF_ERR_ARG;
     return sample_bits(ctx, gen_keyed(key32, nonce, stream), first_row, rows, cols, stride_bytes, out_dev);
+}
+int qf_sample_bits_kt_keyed_dev(qf_ctx *ctx, const uint8_t *key32, uint64_t nonce, uint32_t stream, uint64_t first_row, uint64_t rows,
+                                uint32_t cols, size_t kt_stride_bytes, uint8_t *out_dev) {
+    if (!key32) return QF_ERR_ARG;
+    return sample_bits_kt(ctx, gen_keyed(key32, nonce, stream), first_row, rows, cols, kt_stride_bytes, out_dev);
 }
 int qf_sample_noise_keyed_dev(qf_ctx *ctx, const uint8_t *key32, uint64_t nonce, uint32_t stream, uint64_t first, uint64_t count,
                               uint32_t q, uint32_t W, uint32_t *out_dev) {

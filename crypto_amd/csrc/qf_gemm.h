@@ -8,7 +8,8 @@ struct QfGemmArgs {
     uint32_t ks;             // k-steps (multiple of QF_KS)
     uint32_t rows;           // key rows (= output row length)
     const uint8_t *xbits;    // BITS: bit-packed rows
-    size_t xstride;          // BITS: row stride in bytes (multiple of 16)
+    size_t xstride;          // BITS: row stride in bytes (multiple of 16); k-tile-major bits: bytes between the planes of two k-tiles
+    uint32_t xkt;            // BITS: 1 = k-tile-major (QF_X_BITS_KT): the 16 bytes of row b, k-tile t at t * xstride + b * 16
     const int8_t *rem_planes;// bit operands: packed remainder block of the key [ks][64][16], or null
     uint32_t rem_rows;       //   its rows (rows mod 32)
     const int8_t *xplanes;   // PLANES: batch digit planes, fragment order [mb][ks][xlb_total][64][16]

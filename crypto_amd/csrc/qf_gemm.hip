@@ -867,15 +867,23 @@ __device__ __forceinline__ void qf_gemm_body16(const QfGemmArgs &a, const uint32
 
     // batch operand: the 128 bits per k-tile of message rows 16*mg + lc (inline-asm loads, see QF_LOAD_AT),
     // addressed as (uniform base of the workgroup's first message row) + (32-bit per-lane offset)
+    // Row-major bits (QF_X_BITS): a row's k-tiles are consecutive 16-byte words, rows a.xstride apart -- a wave's request for its
+    // 32 rows touches 32 different 128-byte lines.  K-tile-major bits (QF_X_BITS_KT): the words of one k-tile are consecutive over
+    // the rows, planes a.xstride apart -- the same request is 512 contiguous bytes (4 lines): the CU's vector L1 moves 52 instead
+    // of 80 lines per wave and k-tile, Regev cfg2 / SIS 3.5-4 % faster (profiles/r3/gemm_ablation.log).
     const uint64_t tile_row0 = (uint64_t)bx * QF_NW * 32;
-    const uint8_t *xbase = PL ? nullptr : a.xbits + (tile_row0 < a.B ? tile_row0 : a.B - 1) * a.xstride;
+    const size_t xrowb = a.xkt ? (size_t)16 : a.xstride;            // bytes between consecutive rows
+    const size_t xkt_s = a.xkt ? a.xstride : (size_t)0;             // per k-tile: advance of the uniform base ...
+    const uint32_t xkt_v = a.xkt ? 0u : 16u;                        // ... and of the per-lane offset,
+    const size_t xkt_vlim = a.xkt ? (size_t)0 : a.xstride - 16;     // which stays inside the row
+    const uint8_t *xbase = PL ? nullptr : a.xbits + (tile_row0 < a.B ? tile_row0 : a.B - 1) * xrowb;
     uint32_t xoff[2] = {0, 0};
     if constexpr (!PL) {
 #pragma unroll
     for (int mg = 0; mg < 2; mg++) {
         const uint64_t mrow_l = mb0 * 32 + 16 * mg + lc;
         const uint64_t mrow_c = mrow_l < a.B ? mrow_l : a.B - 1;
-        xoff[mg] = (uint32_t)((mrow_c - (tile_row0 < a.B ? tile_row0 : a.B - 1)) * a.xstride);   // < 256 rows
+        xoff[mg] = (uint32_t)((mrow_c - (tile_row0 < a.B ? tile_row0 : a.B - 1)) * xrowb);   // < 256 rows
     }
     }
     v4i at[2][2];
@@ -898,10 +906,11 @@ __device__ __forceinline__ void qf_gemm_body16(const QfGemmArgs &a, const uint32
                 asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(atp[set_][mg_][sp_])         \
                              : "v"(poff[mg_] + ((uint32_t)(kt_) * QF_KS + 2 * sp_) * pstep), "s"(pbase) : "memory"); \
     } else {                                                                                      \
+    const uint8_t *xb_ = xbase + (size_t)(kt_) * xkt_s;                                           \
+    size_t off_ = (size_t)(kt_) * xkt_v;                                                          \
+    off_ = off_ <= xkt_vlim ? off_ : xkt_vlim;                                                    \
     _Pragma("unroll") for (int mg_ = 0; mg_ < 2; mg_++) {                                         \
-        size_t off_ = (size_t)(kt_)*16;                                                           \
-        off_ = off_ + 16 <= a.xstride ? off_ : a.xstride - 16;                                    \
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(at[set_][mg_]) : "v"(xoff[mg_] + (uint32_t)off_), "s"(xbase) : "memory"); \
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(at[set_][mg_]) : "v"(xoff[mg_] + (uint32_t)off_), "s"(xb_) : "memory"); \
     } }
 #define QF16_WAIT_AT(set_, n_)                                                                    \
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory");                                     \
@@ -1607,6 +1616,12 @@ static int qf_gemm_dispatch(qf_ctx *ctx, const QfGemmArgs &args) {
         if (w >= 1 && w <= WMAX) best = w;
     }
     if (const char *e = getenv("QF_GEMM_MW")) mw = atoi(e);
+    if (args.xkt) {   // k-tile-major bits: the 16x16x64 body only (every default bit-operand path)
+#ifdef QF_GEMM_MFMA32
+        return qf_fail(ctx, QF_ERR_NOTSUP, "gemm: k-tile-major bits need the 16x16x64 body");
+#endif
+        mw = 1;
+    }
     constexpr bool M2W2 = 2 * 2 * S * 16 <= BUDGET, M2W1 = 2 * 1 * S * 16 <= BUDGET;
     if (mw == 2) {
         if (best >= 2) { if constexpr (M2W2) return qf_gemm_dispatch_wn<LA, LB, 2, 2, BITS>(ctx, args); }
@@ -1650,6 +1665,7 @@ int qf_launch_gemm(qf_ctx *ctx, const qf_key *key, const void *X, int x_is_bits,
     a.kplanes = key->planes; a.rb = key->rb; a.ks = key->ks; a.rows = key->rows;
     a.rem_planes = (x_is_bits && lb == 1) ? key->rem_planes : nullptr; a.rem_rows = key->rem_rows;
     a.xbits = x_is_bits ? (const uint8_t *)X : nullptr;
+    a.xkt = x_is_bits == 2;   // k-tile-major
     a.xstride = x_stride;
     a.xplanes = x_is_bits ? nullptr : (const int8_t *)X;
     a.mchunk = 0;

@@ -138,6 +138,7 @@ int qf_launch_dot_decode(qf_ctx *ctx, const uint32_t *w, uint32_t n, const QfMod
                          uint64_t B, uint8_t *bits);
 // qf_sampler.hip
 int qf_launch_sample_uniform(qf_ctx *ctx, QfGen base, uint64_t first, uint64_t count, uint32_t q, uint32_t *out);
+int qf_launch_sample_bits_kt(qf_ctx *ctx, QfGen base, uint64_t first_row, uint64_t rows, uint32_t cols, size_t kt_stride, uint8_t *out);
 int qf_launch_sample_bits(qf_ctx *ctx, QfGen base, uint64_t first_row, uint64_t rows, uint32_t cols,
                           uint32_t stride_bytes, uint8_t *out);
 int qf_launch_sample_cdt(qf_ctx *ctx, QfGen base, uint64_t first, uint64_t count, const QfMod &mod,

@@ -57,6 +57,29 @@ __global__ __launch_bounds__(256) void qf_sample_bits16_kernel(QfGen base, uint6
     }
 }
 
+// The same bits written k-tile-major (QF_X_BITS_KT): the 16-byte word of row r, k-tile g goes to g * kt_stride + 16 r.
+// A thread per row (consecutive rows = consecutive words), blockIdx.y = k-tile; the draws are those of the row-major kernel.
+__global__ __launch_bounds__(256) void qf_sample_bits_kt_kernel(QfGen base, uint64_t first_row, uint64_t rows, uint32_t cols,
+                                                                size_t kt_stride, uint8_t *__restrict__ out) {
+    const uint32_t g = blockIdx.y;
+    const uint32_t w64 = (cols + 63) / 64;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t v[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const uint32_t j0 = (2 * g + t) * 64;
+            v[t] = 0;
+            if (j0 < cols) {
+                v[t] = qf_gen64(base, (first_row + r) * w64 + 2 * g + t);
+                if (cols - j0 < 64) v[t] &= (1ull << (cols - j0)) - 1ull;
+            }
+        }
+        uint4 o;
+        o.x = (uint32_t)v[0]; o.y = (uint32_t)(v[0] >> 32); o.z = (uint32_t)v[1]; o.w = (uint32_t)(v[1] >> 32);
+        *(uint4 *)(out + (size_t)g * kt_stride + r * 16) = o;
+    }
+}
+
 __global__ void qf_sample_noise_kernel(QfGen base, uint64_t first, uint64_t count, QfMod mod, uint32_t W,
                                        uint32_t *__restrict__ out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -109,6 +132,15 @@ int qf_launch_sample_bits(qf_ctx *ctx, QfGen base, uint64_t first_row, uint64_t 
     } else
     hipLaunchKernelGGL(qf_sample_bits_kernel, dim3(sampler_grid(rows * (stride_bytes / 4))), dim3(256), 0, ctx->stream,
                        base, first_row, rows, cols, stride_bytes, out);
+    QF_HIP(ctx, hipGetLastError());
+    return QF_OK;
+}
+int qf_launch_sample_bits_kt(qf_ctx *ctx, QfGen base, uint64_t first_row, uint64_t rows, uint32_t cols, size_t kt_stride, uint8_t *out) {
+    if (!rows || !cols) return QF_OK;
+    const uint32_t ntiles = (cols + 127) / 128;
+    uint64_t gx = (rows + 255) / 256;
+    while (gx > 1 && gx * ntiles > 256 * 64) gx = (gx + 1) / 2;   // enough waves to fill the chip, rows strided
+    hipLaunchKernelGGL(qf_sample_bits_kt_kernel, dim3((unsigned)gx, ntiles), dim3(256), 0, ctx->stream, base, first_row, rows, cols, kt_stride, out);
     QF_HIP(ctx, hipGetLastError());
     return QF_OK;
 }

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import QfError, X_BITS, X_I32, X_U32  # noqa: F401
+from ._lib import QfError, X_BITS, X_BITS_KT, X_I32, X_U32  # noqa: F401
 
 
 def _check(ctx_handle, rc: int):
@@ -144,15 +144,33 @@ class Context:
                msg: Optional[torch.Tensor] = None, x_digits: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if out is None:
             out = self.empty_u32(B, key.rows)
-        stride = X.stride(0) * X.element_size() if X.dim() == 2 else 0
-        if B and X.dim() != 2:
-            raise QfError(_lib.QF_ERR_DIM, "batch operand must be 2-D (message-major)")
+        if kind == X_BITS_KT:
+            # k-tile-major bits (bits_to_kt): (ceil(cols/128), >= B, 16) uint8, planes X.stride(0) bytes apart
+            if B and (X.dim() != 3 or X.shape[2] != 16 or X.stride(1) != 16 or X.stride(2) != 1 or X.element_size() != 1
+                      or X.shape[0] < (key.cols + 127) // 128 or X.shape[1] < B):
+                raise QfError(_lib.QF_ERR_DIM, "k-tile-major bits: (ceil(cols/128), >= B, 16) uint8 planes expected")
+            stride = X.stride(0) if B else 0
+        else:
+            stride = X.stride(0) * X.element_size() if X.dim() == 2 else 0
+            if B and X.dim() != 2:
+                raise QfError(_lib.QF_ERR_DIM, "batch operand must be 2-D (message-major)")
         if addend is not None and tuple(addend.shape) != (B, key.rows):
             raise QfError(_lib.QF_ERR_DIM, "addend must be B x rows")
         rc = self.lib.qf_matmul_modq_dev(self.h, key.h, X.data_ptr() if B else None, kind, stride, x_digits, B,
                                          addend.data_ptr() if addend is not None else None,
                                          msg.data_ptr() if msg is not None else None, out.data_ptr())
         _check(self.h, rc)
+        return out
+
+    def bits_to_kt(self, X: torch.Tensor, B: int, cols: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Bit rows (B, stride) -> k-tile-major planes (ceil(cols/128), B, 16): the operand form X_BITS_KT of matmul."""
+        assert X.is_cuda and X.dim() == 2 and X.element_size() == 1 and X.stride(1) == 1
+        nt = (cols + 127) // 128
+        if out is None:
+            out = torch.empty((nt, B, 16), dtype=torch.uint8, device=X.device)
+        assert out.dim() == 3 and out.shape[0] >= nt and out.shape[1] >= B and out.shape[2] == 16 and out.stride(1) == 16
+        _check(self.h, self.lib.qf_bits_to_kt_dev(self.h, X.data_ptr() if B else None, X.stride(0), B, cols,
+                                                  out.data_ptr() if B else None, out.stride(0)))
         return out
 
     def matvec(self, key: "Key", x) -> np.ndarray:
@@ -256,6 +274,20 @@ class Context:
             rc = self.lib.qf_sample_bits_keyed_dev(self.h, k[0], k[1], stream, first_row, rows, cols, stride, out.data_ptr())
         else:
             rc = self.lib.qf_sample_bits_dev(self.h, seed, stream, first_row, rows, cols, stride, out.data_ptr())
+        _check(self.h, rc)
+        return out
+
+    def sample_bits_kt(self, seed, stream, first_row, rows, cols, out=None):
+        """The bit rows of sample_bits, written k-tile-major: (ceil(cols/128), rows, 16) uint8 (operand kind X_BITS_KT)."""
+        nt = (cols + 127) // 128
+        if out is None:
+            out = torch.empty((nt, rows, 16), dtype=torch.uint8, device=self.device)
+        assert out.dim() == 3 and out.shape[0] >= nt and out.shape[1] >= rows and out.shape[2] == 16 and out.stride(1) == 16
+        k = self._keyed(seed)
+        if k:
+            rc = self.lib.qf_sample_bits_kt_keyed_dev(self.h, k[0], k[1], stream, first_row, rows, cols, out.stride(0), out.data_ptr())
+        else:
+            rc = self.lib.qf_sample_bits_kt_dev(self.h, seed, stream, first_row, rows, cols, out.stride(0), out.data_ptr())
         _check(self.h, rc)
         return out
 

@@ -228,6 +228,12 @@ class Randomness {
         dev_->check(seed_.keyed ? qf_sample_bits_keyed_dev(dev_->ctx(), seed_.key, seed_.seed, stream, f, rows, cols, stride, out_dev)
                                 : qf_sample_bits_dev(dev_->ctx(), seed_.seed, stream, f, rows, cols, stride, out_dev));
     }
+    // the same rows written k-tile-major (QF_X_BITS_KT planes, kt_stride bytes apart)
+    void bits_kt_dev(uint32_t stream, uint64_t rows, uint32_t cols, size_t kt_stride, uint8_t *out_dev) {
+        const uint64_t f = take(stream, rows);
+        dev_->check(seed_.keyed ? qf_sample_bits_kt_keyed_dev(dev_->ctx(), seed_.key, seed_.seed, stream, f, rows, cols, kt_stride, out_dev)
+                                : qf_sample_bits_kt_dev(dev_->ctx(), seed_.seed, stream, f, rows, cols, kt_stride, out_dev));
+    }
     // ---- the same draws brought to the host
     std::vector<uint32_t> uniform(uint32_t stream, uint64_t count, uint32_t q) {
         DevBuf<uint32_t> b(*dev_, count);
@@ -406,6 +412,19 @@ class Regev : public PKEncryptionScheme<Regev, MatZq, MatZq, MatZq> {
         DevBuf<uint8_t> dx(*dev, x_bits), dm(*dev, msg_bits);
         DevBuf<uint32_t> out(*dev, B * (n + 1));
         dev->check(qf_matmul_modq_dev(dev->ctx(), k, dx.get(), QF_X_BITS, bit_stride(m), 1, B, nullptr, dm.get(), out.get()));
+        return out;
+    }
+    // The same with x drawn on the device as Regev::enc does (regev.rs:401): stream 3 of the scheme's generator, written
+    // k-tile-major (the form kernel (a) reads fastest: no layout pass, 3.5-4 % faster product).
+    DevBuf<uint32_t> enc_batch(const MatZq &pk, const std::vector<uint8_t> &msg_bits) {
+        check_pk(pk);
+        const uint64_t B = msg_bits.size();
+        qf_key *k = dev->cached_key(pk);
+        const size_t planes = ((size_t)m + 127) / 128, kt_stride = (size_t)B * 16;
+        DevBuf<uint8_t> dx(*dev, planes * kt_stride), dm(*dev, msg_bits);
+        DevBuf<uint32_t> out(*dev, B * (n + 1));
+        rng.bits_kt_dev(3, B, m, kt_stride, dx.get());
+        dev->check(qf_matmul_modq_dev(dev->ctx(), k, dx.get(), QF_X_BITS_KT, kt_stride, 1, B, nullptr, dm.get(), out.get()));
         return out;
     }
     std::vector<uint8_t> dec_batch(const MatZq &sk, const uint32_t *C_dev, uint64_t B) {

@@ -33,6 +33,7 @@ pub const QF_ERR_NOTSUP: c_int = 6;
 pub const QF_X_BITS: c_int = 0;
 pub const QF_X_U32: c_int = 1;
 pub const QF_X_I32: c_int = 2;
+pub const QF_X_BITS_KT: c_int = 3;
 
 extern "C" {
     // ---- context
@@ -58,6 +59,7 @@ extern "C" {
 
     // ---- kernel (a): batched product on int8 MFMA
     pub fn qf_matmul_modq_dev(ctx: *mut qf_ctx, key: *const qf_key, x_dev: *const c_void, x_kind: c_int, x_stride_bytes: usize, x_digits: c_int, b: u64, addend_dev: *const u32, msg_dev: *const u8, out_dev: *mut u32) -> c_int;
+    pub fn qf_bits_to_kt_dev(ctx: *mut qf_ctx, bits_dev: *const u8, stride_bytes: usize, b: u64, cols: u32, kt_dev: *mut u8, kt_stride_bytes: usize) -> c_int;
 
     // ---- kernel (c): single-message products
     pub fn qf_matvec_modq_host(ctx: *mut qf_ctx, key: *const qf_key, x_host: *const u32, y_host: *mut u32) -> c_int;
@@ -86,10 +88,12 @@ extern "C" {
     // ---- counter-mode generator: seeded (SplitMix64) and keyed (ChaCha20)
     pub fn qf_sample_uniform_dev(ctx: *mut qf_ctx, seed: u64, stream: u32, first: u64, count: u64, q: u32, out_dev: *mut u32) -> c_int;
     pub fn qf_sample_bits_dev(ctx: *mut qf_ctx, seed: u64, stream: u32, first_row: u64, rows: u64, cols: u32, stride_bytes: u32, out_dev: *mut u8) -> c_int;
+    pub fn qf_sample_bits_kt_dev(ctx: *mut qf_ctx, seed: u64, stream: u32, first_row: u64, rows: u64, cols: u32, kt_stride_bytes: usize, out_dev: *mut u8) -> c_int;
     pub fn qf_sample_noise_dev(ctx: *mut qf_ctx, seed: u64, stream: u32, first: u64, count: u64, q: u32, w: u32, out_dev: *mut u32) -> c_int;
     pub fn qf_sample_discrete_gauss_dev(ctx: *mut qf_ctx, seed: u64, stream: u32, first: u64, count: u64, q: u32, n: u32, s: f64, out_dev: *mut u32) -> c_int;
     pub fn qf_sample_uniform_keyed_dev(ctx: *mut qf_ctx, key32: *const u8, nonce: u64, stream: u32, first: u64, count: u64, q: u32, out_dev: *mut u32) -> c_int;
     pub fn qf_sample_bits_keyed_dev(ctx: *mut qf_ctx, key32: *const u8, nonce: u64, stream: u32, first_row: u64, rows: u64, cols: u32, stride_bytes: u32, out_dev: *mut u8) -> c_int;
+    pub fn qf_sample_bits_kt_keyed_dev(ctx: *mut qf_ctx, key32: *const u8, nonce: u64, stream: u32, first_row: u64, rows: u64, cols: u32, kt_stride_bytes: usize, out_dev: *mut u8) -> c_int;
     pub fn qf_sample_noise_keyed_dev(ctx: *mut qf_ctx, key32: *const u8, nonce: u64, stream: u32, first: u64, count: u64, q: u32, w: u32, out_dev: *mut u32) -> c_int;
     pub fn qf_sample_discrete_gauss_keyed_dev(ctx: *mut qf_ctx, key32: *const u8, nonce: u64, stream: u32, first: u64, count: u64, q: u32, n: u32, s: f64, out_dev: *mut u32) -> c_int;
 

@@ -89,6 +89,15 @@ int main() {
         std::vector<uint8_t> bits = r.dec_batch(sk, C.get(), B);
         qfo_dot_decode_batch(sk.e.data(), r.n, r.q, Cref.data(), B, bits_ref.data());
         CHECK(bits == bits_ref && bits == msg);
+        // x drawn on the device, k-tile-major (QF_X_BITS_KT): the same ciphertexts as the oracle computes from the rows
+        // the generator gives for that position of stream 3
+        Regev rs(dev, r.n, r.m, r.q, r.alpha, Seed(MASTER_SEED));
+        const uint64_t pos = rs.randomness().take(3, 0);
+        DevBuf<uint32_t> C2 = rs.enc_batch(pk, msg);
+        qfo_sample_bits(MASTER_SEED, 3, pos, B, r.m, bit_stride(r.m), xb.data());
+        qfo_matmul_batch(pk.e.data(), r.n + 1, r.m, r.q, xb.data(), 0, bit_stride(r.m), B, nullptr, msg.data(), Cref.data());
+        CHECK(C2.download() == Cref);
+        CHECK(rs.dec_batch(sk, C2.get(), B) == msg);
     });
     run("regev_panics", [&] {
         Regev r = Regev::default_(dev);

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import coracle as co
-from crypto_amd.device import QfError, X_BITS, X_I32, X_U32, bit_stride, pack_bits
+from crypto_amd.device import QfError, X_BITS, X_BITS_KT, X_I32, X_U32, bit_stride, pack_bits
 
 pytestmark = pytest.mark.gpu
 SEED = 0x5146414C4C
@@ -91,6 +91,55 @@ def test_matmul_bits_regev_shape(ctx, n, m, q, B):
     out = ctx.matmul(key, ctx.to_dev_u8(xb), X_BITS, B, msg=ctx.to_dev_u8(msg))
     ref = co.matmul_batch(pk, q, xb, co.X_BITS, B, msg=msg)
     assert np.array_equal(ctx.to_host_u32(out), ref)
+
+
+@pytest.mark.parametrize("n,m,q,B", [(13, 154, 1427, 70), (50, 867, 124991, 300), (256, 6168, 16777213, 513), (3, 16, 13, 5),
+                                     (64, 1000, 2147483629, 40), (31, 129, 251, 33), (47, 300, 40009, 70), (41, 500, 8380417, 257),
+                                     (100, 640, 8380417, 300), (7, 99, 1000003, 19), (511, 11776, 8380417, 1000), (1, 1, 7, 1),
+                                     (256, 6168, 16777213, 256 * 3 + 93)])
+def test_matmul_bits_k_tile_major(ctx, n, m, q, B):
+    """The same products from k-tile-major bits (QF_X_BITS_KT): qf_bits_to_kt_dev against a host transposition, the
+    product against the row-major one and the oracle; planes wider than the batch, addend + message; a plane too
+    short for the batch is refused."""
+    pk = co.sample_uniform(SEED, 1, 0, (n + 1) * m, q).reshape(n + 1, m)
+    st = bit_stride(m)
+    nt = (m + 127) // 128
+    xb = co.sample_bits(SEED, 3, 0, B, m, st)
+    msg = (co.sample_uniform(SEED, 5, 0, B, 2)).astype(np.uint8)
+    add = co.sample_uniform(SEED, 4, 0, B * (n + 1), q).reshape(B, n + 1)
+    key = ctx.key_upload(pk, q)
+    xd = ctx.to_dev_u8(xb)
+    kt = ctx.bits_to_kt(xd, B, m)
+    assert tuple(kt.shape) == (nt, B, 16)
+    assert np.array_equal(kt.cpu().numpy(), np.ascontiguousarray(xb[:, :nt * 16].reshape(B, nt, 16).transpose(1, 0, 2)))
+    ref = co.matmul_batch(pk, q, xb, co.X_BITS, B, msg=msg)
+    out = ctx.matmul(key, kt, X_BITS_KT, B, msg=ctx.to_dev_u8(msg))
+    assert np.array_equal(ctx.to_host_u32(out), ref)
+    assert torch.equal(out, ctx.matmul(key, xd, X_BITS, B, msg=ctx.to_dev_u8(msg)))
+    # planes longer than the batch (garbage behind row B-1 must not matter), with an addend
+    wide = torch.full((nt, B + 37, 16), 0xA5, dtype=torch.uint8, device=kt.device)
+    ctx.bits_to_kt(xd, B, m, out=wide)
+    ref2 = co.matmul_batch(pk, q, xb, co.X_BITS, B, addend=add, msg=msg)
+    out2 = ctx.matmul(key, wide, X_BITS_KT, B, addend=ctx.to_dev_u32(add), msg=ctx.to_dev_u8(msg))
+    assert np.array_equal(ctx.to_host_u32(out2), ref2)
+    if B > 1:
+        with pytest.raises(QfError):
+            ctx.matmul(key, kt[:, :B - 1], X_BITS_KT, B)
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 1), (3, 64), (5, 65), (70000, 129), (300, 6168), (9, 867), (257, 128), (1000, 11776)])
+def test_bit_sampler_k_tile_major(ctx, rows, cols):
+    """qf_sample_bits_kt_dev / _keyed: the rows of the row-major sampler (= the oracle's), word (row, k-tile) at plane k-tile."""
+    nt = (cols + 127) // 128
+    st = bit_stride(cols)
+    for seed, ref in ((SEED, co.sample_bits(SEED, 3, 11, rows, cols, st)),
+                      ((bytes(range(32)), 5), co.sample_bits((bytes(range(32)), 5), 3, 11, rows, cols, st))):
+        kt = ctx.sample_bits_kt(seed, 3, 11, rows, cols)
+        assert tuple(kt.shape) == (nt, rows, 16)
+        assert np.array_equal(kt.cpu().numpy(), np.ascontiguousarray(ref.reshape(rows, nt, 16).transpose(1, 0, 2)))
+    wide = torch.full((nt, rows + 5, 16), 0x5A, dtype=torch.uint8, device=kt.device)
+    ctx.sample_bits_kt(SEED, 3, 11, rows, cols, out=wide)
+    assert torch.equal(wide[:, :rows], ctx.sample_bits_kt(SEED, 3, 11, rows, cols)) and bool((wide[:, rows:] == 0x5A).all())
 
 
 @pytest.mark.parametrize("n,q,W,B,digits", [(10, 983, 3, 50, 0), (10, 983, 3, 50, 1), (64, 1073741789, 2000, 70, 3),
