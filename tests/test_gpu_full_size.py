@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import coracle as co
-from crypto_amd.device import X_BITS, X_U32
+from crypto_amd.device import X_BITS, X_BITS_KT, X_U32
 
 pytestmark = pytest.mark.gpu
 SEED = 0x5146414C4C
@@ -58,6 +58,13 @@ def test_regev_config2(ctx, n, m, q, B):
     last = np.arange(256 * 17, Bp)
     ref = co.matmul_batch(ctx.to_host_u32(pk), q, ctx.to_host_u8(x[last]), co.X_BITS, len(last), msg=ctx.to_host_u8(msg[last]), mt=True)
     assert np.array_equal(ctx.to_host_u32(cp[last]), ref)
+    # the same bits k-tile-major (what bench.py keeps resident): drawn in that form and converted from the rows -- one image;
+    # the whole batch and the batch ending inside a tile (planes of the full batch: rows behind Bp are simply not read)
+    xk = ctx.sample_bits_kt(SEED, 3, 0, B, m)
+    assert torch.equal(xk, ctx.bits_to_kt(x, B, m))
+    assert torch.equal(ctx.matmul(key, xk, X_BITS_KT, B, msg=msg), c)
+    guard.fill_(-1)
+    assert torch.equal(ctx.matmul(key, xk, X_BITS_KT, Bp, msg=msg[:Bp], out=guard[:Bp]), c[:Bp]) and bool((guard[Bp] == -1).all())
 
 
 @pytest.mark.timeout(300)
@@ -77,6 +84,9 @@ def test_sis_config3(ctx):
     rows = _rows(B, 24)
     ref = co.matmul_batch(ctx.to_host_u32(A), q, ctx.to_host_u8(x[rows]), co.X_BITS, len(rows), mt=True)
     assert np.array_equal(ctx.to_host_u32(d[rows]), ref)
+    xk = ctx.bits_to_kt(x, B, m)                                              # the same inputs k-tile-major
+    assert torch.equal(ctx.matmul(key, xk, X_BITS_KT, B), d)
+    del xk
     # a collision of the hash: x and x' = x with two equal... (none to construct without a trapdoor) -- instead
     # homomorphism on Z_q inputs at the secondary size: A(v1 + v2) = A v1 + A v2
     B2 = 1 << 14
