@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QF_LIB_PATH") or os.path.join(_HERE, "lib", "libqfgpu.so")  # override: diagnostic builds only
 
 QF_OK, QF_ERR_ARG, QF_ERR_DIM, QF_ERR_MODULUS, QF_ERR_DEVICE, QF_ERR_RANGE, QF_ERR_NOTSUP = range(7)
-X_BITS, X_U32, X_I32, X_BITS_KT = 0, 1, 2, 3
+X_BITS, X_U32, X_I32, X_BITS_KT, X_PLANES = 0, 1, 2, 3, 4
 
 _ERR_NAMES = {1: "QF_ERR_ARG", 2: "QF_ERR_DIM", 3: "QF_ERR_MODULUS", 4: "QF_ERR_DEVICE",
               5: "QF_ERR_RANGE", 6: "QF_ERR_NOTSUP"}
@@ -49,6 +49,8 @@ SYMBOLS = {
     "qf_key_replicate": (_i, [_pp, _i, _vp, _pp]),
     "qf_matmul_modq_dev": (_i, [_vp, _vp, _vp, _i, _sz, _i, _u64, _vp, _vp, _vp]),
     "qf_bits_to_kt_dev": (_i, [_vp, _vp, _sz, _u64, _u32, _vp, _sz]),
+    "qf_operand_planes_bytes": (_sz, [_vp, _u64, _i]),
+    "qf_recode_planes_dev": (_i, [_vp, _vp, _vp, _i, _sz, _i, _u64, _vp]),
     "qf_matvec_modq_host": (_i, [_vp, _vp, _vp, _vp]),
     "qf_vecmat_modq_host": (_i, [_vp, _vp, _vp, _vp]),
     "qf_matvec_modq_dev": (_i, [_vp, _vp, _vp, _vp]),

@@ -374,6 +374,35 @@ int qf_bits_to_kt_dev(qf_ctx *ctx, const uint8_t *bits_dev, size_t stride_bytes,
     return QF_OK;
 }
 
+// ------------------------------------------------------------------ wide operand -> digit planes, ahead of the product
+size_t qf_operand_planes_bytes(const qf_key *key, uint64_t B, int digits) {
+    if (!key || digits < 1 || digits > key->la) return 0;
+    return (size_t)((B + 31) / 32) * key->ks * (size_t)digits * 1024;
+}
+int qf_recode_planes_dev(qf_ctx *ctx, const qf_key *key, const void *X_dev, int x_kind, size_t x_stride_bytes, int digits,
+                         uint64_t B, int8_t *planes_dev) {
+    if (!ctx || !key) return QF_ERR_ARG;
+    if (B == 0) return QF_OK;
+    if (!X_dev || !planes_dev || ((uintptr_t)planes_dev & 15)) return qf_fail(ctx, QF_ERR_ARG, "recode planes: null or misaligned operand");
+    if (key->device != ctx->device) return qf_fail(ctx, QF_ERR_ARG, "recode planes: key lives on another device");
+    if (x_kind != QF_X_U32 && x_kind != QF_X_I32) return qf_fail(ctx, QF_ERR_ARG, "recode planes: operand must be QF_X_U32 or QF_X_I32");
+    if (x_stride_bytes < (size_t)key->cols * 4 || x_stride_bytes % 4) return qf_fail(ctx, QF_ERR_DIM, "recode planes: operand rows shorter than the key's column count");
+    if (digits < 1 || digits > key->la) return qf_fail(ctx, QF_ERR_ARG, "recode planes: digits must be 1..digits of q");
+    if (B > 0xFFFFFFFFull) return qf_fail(ctx, QF_ERR_NOTSUP, "recode planes: batch too large");
+    QF_BIND(ctx);
+    int rc = qf_launch_recode(ctx, X_dev, x_kind, x_stride_bytes, (uint32_t)B, key->cols, key->mod, digits, key->ks, planes_dev, ctx->flag);
+    if (rc) return rc;
+    if (digits < key->la) {   // the promise: read the device's verdict before anybody can use the planes
+        QF_HIP(ctx, hipMemcpyAsync(ctx->hflag, ctx->flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+        QF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (*(volatile uint32_t *)ctx->hflag != 0) {
+            QF_HIP(ctx, hipMemsetAsync(ctx->flag, 0, 4, ctx->stream));
+            return qf_fail(ctx, QF_ERR_RANGE, "recode planes: an entry does not fit the promised digits");
+        }
+    }
+    return QF_OK;
+}
+
 // ------------------------------------------------------------------ kernel (a)
 int qf_matmul_modq_dev(qf_ctx *ctx, const qf_key *key, const void *X_dev, int x_kind, size_t x_stride_bytes,
                        int x_digits, uint64_t B, const uint32_t *addend_dev, const uint8_t *msg_dev,
@@ -393,6 +422,12 @@ int qf_matmul_modq_dev(qf_ctx *ctx, const qf_key *key, const void *X_dev, int x_
         if (x_stride_bytes % 16 || ((uintptr_t)X_dev & 15)) return qf_fail(ctx, QF_ERR_ARG, "matmul: k-tile planes must be 16-byte aligned/strided");
         if (x_stride_bytes / 16 < B) return qf_fail(ctx, QF_ERR_DIM, "matmul: k-tile planes shorter than the batch");
         return qf_launch_gemm(ctx, key, X_dev, 2, x_stride_bytes, 1, B, addend_dev, msg_dev, out_dev);
+    }
+    if (x_kind == QF_X_PLANES) {
+        if (x_digits < 1 || x_digits > key->la) return qf_fail(ctx, QF_ERR_ARG, "matmul: digit planes need x_digits = their digit count (1..digits of q)");
+        if ((uintptr_t)X_dev & 15) return qf_fail(ctx, QF_ERR_ARG, "matmul: digit planes must be 16-byte aligned");
+        if (B > 0xFFFFFFFFull) return qf_fail(ctx, QF_ERR_NOTSUP, "matmul: batch too large");
+        return qf_launch_gemm(ctx, key, X_dev, 0, 0, x_digits, B, addend_dev, msg_dev, out_dev);
     }
     if (x_kind != QF_X_U32 && x_kind != QF_X_I32) return qf_fail(ctx, QF_ERR_ARG, "matmul: unknown operand kind");
     if (x_stride_bytes < (size_t)key->cols * 4 || x_stride_bytes % 4) return qf_fail(ctx, QF_ERR_DIM, "matmul: operand rows shorter than the key's column count");

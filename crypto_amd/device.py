@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import QfError, X_BITS, X_BITS_KT, X_I32, X_U32  # noqa: F401
+from ._lib import QfError, X_BITS, X_BITS_KT, X_I32, X_PLANES, X_U32  # noqa: F401
 
 
 def _check(ctx_handle, rc: int):
@@ -144,7 +144,13 @@ class Context:
                msg: Optional[torch.Tensor] = None, x_digits: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if out is None:
             out = self.empty_u32(B, key.rows)
-        if kind == X_BITS_KT:
+        if kind == X_PLANES:
+            # digit planes of recode_planes for this key and batch: x_digits = their digit count
+            need = self.lib.qf_operand_planes_bytes(key.h, B, x_digits)
+            if B and (need == 0 or X.element_size() != 1 or not X.is_contiguous() or X.numel() < need):
+                raise QfError(_lib.QF_ERR_DIM, "digit planes: a contiguous int8 buffer of qf_operand_planes_bytes(key, B, x_digits) bytes expected")
+            stride = 0
+        elif kind == X_BITS_KT:
             # k-tile-major bits (bits_to_kt): (ceil(cols/128), >= B, 16) uint8, planes X.stride(0) bytes apart
             if B and (X.dim() != 3 or X.shape[2] != 16 or X.stride(1) != 16 or X.stride(2) != 1 or X.element_size() != 1
                       or X.shape[0] < (key.cols + 127) // 128 or X.shape[1] < B):
@@ -160,6 +166,20 @@ class Context:
                                          addend.data_ptr() if addend is not None else None,
                                          msg.data_ptr() if msg is not None else None, out.data_ptr())
         _check(self.h, rc)
+        return out
+
+    def recode_planes(self, key: "Key", X: torch.Tensor, kind: int, B: int, digits: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """A wide operand (B x cols int32 rows, X_U32 / X_I32) -> the signed-digit planes kernel (a) consumes (operand kind
+        X_PLANES, x_digits = digits).  Raises QfError(QF_ERR_RANGE) if an entry does not fit the promised digits."""
+        assert X.is_cuda and X.dim() == 2 and X.element_size() == 4 and X.stride(1) == 1
+        need = self.lib.qf_operand_planes_bytes(key.h, B, digits)
+        if need == 0 and B:
+            raise QfError(_lib.QF_ERR_ARG, "recode_planes: digits must be 1..digits of q")
+        if out is None:
+            out = torch.empty((need,), dtype=torch.int8, device=X.device)
+        assert out.numel() >= need and out.element_size() == 1 and out.is_contiguous()
+        _check(self.h, self.lib.qf_recode_planes_dev(self.h, key.h, X.data_ptr() if B else None, kind, X.stride(0) * 4, digits, B,
+                                                     out.data_ptr() if B else None))
         return out
 
     def bits_to_kt(self, X: torch.Tensor, B: int, cols: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -53,6 +53,10 @@ enum {
     QF_X_BITS = 0, /* {0,1}^cols bit-packed; row stride multiple of 16 bytes          */
     QF_X_U32 = 1,  /* residues mod q as uint32_t (any value < 2^32 is reduced mod q)  */
     QF_X_I32 = 2,  /* signed integers as int32_t (reduced mod q)                      */
+    QF_X_PLANES = 4, /* signed radix-2^8 digit planes in MFMA fragment order, as qf_recode_planes_dev writes them for
+                        THIS key: x_digits (1..digits of q) planes per k-step; x_stride_bytes is ignored.  The form the
+                        product consumes -- qf_matmul_modq_dev recodes QF_X_U32 / QF_X_I32 operands into it on
+                        every call (LPR cfg4: 0.25 of 2.2 ms) */
     QF_X_BITS_KT = 3 /* {0,1}^cols bit-packed, k-tile-major: the 16 bytes that hold columns 128t..128t+127 of row b
                         sit at byte t * x_stride_bytes + 16 b (ceil(cols/128) planes of >= B words; what
                         qf_bits_to_kt_dev writes).  Same product as QF_X_BITS, 3.5-4 % faster on the BASELINE
@@ -130,6 +134,15 @@ int qf_matmul_modq_dev(qf_ctx *ctx, const qf_key *key, const void *X_dev, int x_
  * sis.rs:161-167); a producer that writes the planes itself does not need it. */
 int qf_bits_to_kt_dev(qf_ctx *ctx, const uint8_t *bits_dev, size_t stride_bytes, uint64_t B, uint32_t cols,
                       uint8_t *kt_dev, size_t kt_stride_bytes);
+
+/* A wide batch operand (QF_X_U32 / QF_X_I32 rows) -> the digit planes kernel (a) consumes (QF_X_PLANES), once, for
+ * operands that are multiplied more than once or prepared ahead of the product (LPR::enc's r: lpr.rs:399-420).
+ * digits: 1..digits of q; fewer than q's is a promise that every centred entry fits -- verified here, synchronously:
+ * QF_ERR_RANGE if it does not hold (the planes are then unusable).  planes_dev: qf_operand_planes_bytes(key, B, digits)
+ * bytes (= ceil(B/32) * 4*ceil(cols/128) * digits KiB), 16-byte aligned. */
+size_t qf_operand_planes_bytes(const qf_key *key, uint64_t B, int digits);
+int qf_recode_planes_dev(qf_ctx *ctx, const qf_key *key, const void *X_dev, int x_kind, size_t x_stride_bytes,
+                         int digits, uint64_t B, int8_t *planes_dev);
 
 /* Kernel (c): HBM-streaming single-message products (host vectors in/out, synchronous).
  *   qf_matvec_modq_host : y = key * x          regev.rs:404, lpr.rs:420, sis.rs:166, dual_regev.rs:354

@@ -34,6 +34,7 @@ pub const QF_X_BITS: c_int = 0;
 pub const QF_X_U32: c_int = 1;
 pub const QF_X_I32: c_int = 2;
 pub const QF_X_BITS_KT: c_int = 3;
+pub const QF_X_PLANES: c_int = 4;
 
 extern "C" {
     // ---- context
@@ -59,6 +60,8 @@ extern "C" {
 
     // ---- kernel (a): batched product on int8 MFMA
     pub fn qf_matmul_modq_dev(ctx: *mut qf_ctx, key: *const qf_key, x_dev: *const c_void, x_kind: c_int, x_stride_bytes: usize, x_digits: c_int, b: u64, addend_dev: *const u32, msg_dev: *const u8, out_dev: *mut u32) -> c_int;
+    pub fn qf_operand_planes_bytes(key: *const qf_key, b: u64, digits: c_int) -> usize;
+    pub fn qf_recode_planes_dev(ctx: *mut qf_ctx, key: *const qf_key, x_dev: *const c_void, x_kind: c_int, x_stride_bytes: usize, digits: c_int, b: u64, planes_dev: *mut i8) -> c_int;
     pub fn qf_bits_to_kt_dev(ctx: *mut qf_ctx, bits_dev: *const u8, stride_bytes: usize, b: u64, cols: u32, kt_dev: *mut u8, kt_stride_bytes: usize) -> c_int;
 
     // ---- kernel (c): single-message products

@@ -5,7 +5,8 @@ import pytest
 import torch
 
 from oracle import coracle as co
-from crypto_amd.device import QfError, X_BITS, X_BITS_KT, X_I32, X_U32, bit_stride, pack_bits
+from crypto_amd import _lib
+from crypto_amd.device import QfError, X_BITS, X_BITS_KT, X_I32, X_PLANES, X_U32, bit_stride, pack_bits
 
 pytestmark = pytest.mark.gpu
 SEED = 0x5146414C4C
@@ -155,6 +156,37 @@ def test_matmul_u32_lpr_shape(ctx, n, q, W, B, digits):
     out = ctx.matmul(key, ctx.to_dev_u32(r), X_U32, B, addend=ctx.to_dev_u32(e), msg=ctx.to_dev_u8(msg), x_digits=digits)
     ref = co.matmul_batch(pk, q, r, co.X_U32, B, addend=e, msg=msg)
     assert np.array_equal(ctx.to_host_u32(out), ref)
+
+
+@pytest.mark.parametrize("n,q,W,B,digits", [(10, 983, 3, 50, 1), (64, 1073741789, 2000, 70, 2), (64, 1073741789, 2000, 70, 4), (40, 65521, 30, 35, 1),
+                                            (128, 8380417, 100, 64, 3), (1024, 1073741789, 2319, 300, 2), (230, 7764299, 0, 257, 3)])
+def test_matmul_prerecoded_planes(ctx, n, q, W, B, digits):
+    """Operand kind QF_X_PLANES: qf_recode_planes_dev once, then the product on the planes -- the ciphertexts of the
+    QF_X_U32 path and the oracle (LPR::enc shape, lpr.rs:394-430; W = 0: uniform entries at full width); a promise the
+    entries break is refused with QF_ERR_RANGE, and so are planes with a digit count the key does not have."""
+    pk = co.sample_uniform(SEED, 1, 0, (n + 1) * n, q).reshape(n + 1, n)
+    r = co.sample_noise(SEED, 3, 0, B * n, q, W).reshape(B, n) if W else co.sample_uniform(SEED, 3, 0, B * n, q).reshape(B, n)
+    e = co.sample_uniform(SEED, 4, 0, B * (n + 1), q).reshape(B, n + 1)
+    msg = (co.sample_uniform(SEED, 5, 0, B, 2)).astype(np.uint8)
+    key = ctx.key_upload(pk, q)
+    rd, ed, md = ctx.to_dev_u32(r), ctx.to_dev_u32(e), ctx.to_dev_u8(msg)
+    planes = ctx.recode_planes(key, rd, X_U32, B, digits)
+    out = ctx.matmul(key, planes, X_PLANES, B, addend=ed, msg=md, x_digits=digits)
+    ref = co.matmul_batch(pk, q, r, co.X_U32, B, addend=e, msg=msg)
+    assert np.array_equal(ctx.to_host_u32(out), ref)
+    assert torch.equal(out, ctx.matmul(key, rd, X_U32, B, addend=ed, msg=md, x_digits=digits))
+    assert torch.equal(ctx.matmul(key, planes, X_PLANES, B, x_digits=digits), ctx.matmul(key, rd, X_U32, B))
+    if W and digits < 4 and q > 2 ** 24:
+        big = rd.clone()
+        big[B // 2, n // 3] = q // 2                    # does not fit `digits` signed bytes
+        with pytest.raises(QfError) as err:
+            ctx.recode_planes(key, big, X_U32, B, digits)
+        assert err.value.code == _lib.QF_ERR_RANGE
+        assert torch.equal(ctx.matmul(key, planes, X_PLANES, B, addend=ed, msg=md, x_digits=digits), out)   # the context is fine afterwards
+    with pytest.raises(QfError):
+        ctx.matmul(key, planes, X_PLANES, B, x_digits=0)
+    with pytest.raises(QfError):
+        ctx.recode_planes(key, rd, X_U32, B, 5)
 
 
 def test_matmul_full_width_and_i32(ctx):

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 def _c_to_rust(ctype: str) -> str:
     """One C parameter / return type of include/qfgpu.h as the Rust FFI type that must stand for it."""
     t = re.sub(r"/\*.*?\*/", "", ctype).strip()
-    base = {"int": "c_int", "void": "c_void", "char": "c_char", "uint32_t": "u32", "uint64_t": "u64", "uint8_t": "u8", "int32_t": "i32",
+    base = {"int": "c_int", "void": "c_void", "char": "c_char", "uint32_t": "u32", "uint64_t": "u64", "uint8_t": "u8", "int8_t": "i8", "int32_t": "i32",
             "size_t": "usize", "double": "f64", "float": "f32", "qf_ctx": "qf_ctx", "qf_key": "qf_key", "qf_ring": "qf_ring", "qf_rkey": "qf_rkey"}
     toks = re.findall(r"[A-Za-z_0-9]+|\*", t)
     # C declarators read right to left: "const T *" = pointer to const T; "T *const *" = pointer to const pointer to T
