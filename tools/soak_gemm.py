@@ -4,7 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from oracle import coracle as co
-from crypto_amd.device import Context, X_BITS, X_BITS_KT, X_U32, X_I32, bit_stride
+from crypto_amd.device import Context, X_BITS, X_BITS_KT, X_PLANES, X_U32, X_I32, bit_stride
 
 PRIMES = [7, 16, 251, 257, 12289, 65521, 65537, 8380417, 16777213, 16777259, 1073741789, 2147483629]
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
@@ -18,7 +18,7 @@ for c in range(ncases):
     rows = int(rng.choice([rng.integers(1, 40), rng.integers(60, 140), rng.integers(250, 300)]))
     cols = int(rng.choice([rng.integers(1, 40), rng.integers(100, 140), rng.integers(250, 262), rng.integers(1000, 1100)]))
     B = int(rng.choice([1, 33, 257, 300, 2049, 8193 + int(rng.integers(0, 700))]))
-    kind = int(rng.integers(0, 5))
+    kind = int(rng.integers(0, 6))
     A = co.sample_uniform(SEED, 1, c, rows * cols, q).reshape(rows, cols)
     key = ctx.key_upload(A, q)
     msg = co.sample_uniform(SEED, 5, c, B, 2).astype(np.uint8) if rng.integers(0, 2) else None
@@ -39,6 +39,18 @@ for c in range(ncases):
             ctx.sample_bits_kt(SEED, 3, c, B, cols, out=xk)
         out = ctx.matmul(key, xk, X_BITS_KT, B, addend=de, msg=dm)
         ref = co.matmul_batch(A, q, xb, co.X_BITS, B, addend=E, msg=msg, mt=True)
+    elif kind == 5:   # a wide operand recoded once into digit planes (QF_X_PLANES), product on the planes
+        la = 1
+        while 256 ** la < q: la += 1
+        dg = int(rng.integers(1, la + 1))
+        W = [30, 8000, 2000000, 500000000][dg - 1]
+        if dg == la or 4 * W >= q // 2:
+            X = co.sample_uniform(SEED, 6, c, B * cols, q).reshape(B, cols); dg = la
+        else:
+            X = co.sample_noise(SEED, 3, c, B * cols, q, W).reshape(B, cols)
+        planes = ctx.recode_planes(key, ctx.to_dev_u32(X), X_U32, B, dg)
+        out = ctx.matmul(key, planes, X_PLANES, B, addend=de, msg=dm, x_digits=dg)
+        ref = co.matmul_batch(A, q, X, co.X_U32, B, addend=E, msg=msg, mt=True)
     elif kind == 1:
         X = co.sample_uniform(SEED, 6, c, B * cols, q).reshape(B, cols)
         out = ctx.matmul(key, ctx.to_dev_u32(X), X_U32, B, addend=de, msg=dm)
