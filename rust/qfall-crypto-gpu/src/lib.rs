@@ -220,6 +220,16 @@ impl RegevGpu {
         let key = self.keys.get(&self.dev, pk, false);
         self.dev.check(unsafe { qf_matmul_modq_dev(self.dev.ctx, key, x_bits_dev, QF_X_BITS, stride, 0, b, ptr::null(), msg_bits_dev, out_dev) });
     }
+    /// The same with x drawn on the device as Regev::enc does (regev.rs:401), under `key32` (32 bytes of the OS CSPRNG)
+    /// and `nonce`: the sampler writes the bits k-tile-major (`QF_X_BITS_KT`, the form kernel (a) reads fastest) into
+    /// `planes_dev` = ceil(m/128) planes of 16*b bytes, the caller's device memory like the other buffers.
+    pub fn enc_batch_sampled(&self, pk: &MatZq, key32: &[u8; 32], nonce: u64, first_row: u64, planes_dev: *mut u8, msg_bits_dev: *const u8, b: u64, out_dev: *mut u32) {
+        let key = self.keys.get(&self.dev, pk, false);
+        let m = u32::try_from(&self.m).expect("m fits u32");
+        let kt_stride = 16 * b as usize;
+        self.dev.check(unsafe { qf_sample_bits_kt_keyed_dev(self.dev.ctx, key32.as_ptr(), nonce, 3, first_row, b, m, kt_stride, planes_dev) });
+        self.dev.check(unsafe { qf_matmul_modq_dev(self.dev.ctx, key, planes_dev as *const c_void, QF_X_BITS_KT, kt_stride, 0, b, ptr::null(), msg_bits_dev, out_dev) });
+    }
     /// B ciphertexts (rows of n+1 words in device memory) -> B bytes 0/1
     pub fn dec_batch(&self, sk: &MatZq, c_dev: *const u32, b: u64, bits_dev: *mut u8) {
         let (s, n, _, q) = matzq_to_u32(sk);
